@@ -1,0 +1,83 @@
+"""Drop-in for the sampler half of the reference's `cifar10/compute_fid.py` on the MI355X backend.
+
+`make_gen_1_img` builds the `gen_1_img(unused_latent) -> uint8 [B,3,32,32]` closure that cleanfid's
+`fid.compute_fid(gen=...)` calls (cifar10/compute_fid.py:73-88), with the same flag names
+(`integration_steps`, `integration_method`, `batch_size_fid`, `num_channel`).  With world_size > 1 every rank
+samples its shard and the shards are collected with ONE RCCL all-gather (mi355.dist).  cleanfid itself
+(Inception weights + CIFAR statistics, both downloaded) is not available offline; `main()` reports that.
+"""
+import argparse
+import os
+
+import torch
+
+from mi355 import dist as mdist
+from torchcfm_compat import UNetModelWrapper
+
+
+def build_model(num_channel=128, device="cuda:0", precision=None):
+    """cifar10/compute_fid.py:39-48."""
+    return UNetModelWrapper(dim=(3, 32, 32), num_res_blocks=2, num_channels=num_channel, channel_mult=[1, 2, 2, 2], num_heads=4,
+                            num_head_channels=64, attention_resolutions="16", dropout=0.1, precision=precision).to(device)
+
+
+def load_checkpoint(net, path):
+    """cifar10/compute_fid.py:52-65: take ["ema_model"], strip a 7-char "module." prefix on mismatch."""
+    checkpoint = torch.load(path, map_location="cpu", weights_only=True)
+    state_dict = checkpoint["ema_model"]
+    try:
+        net.load_state_dict(state_dict)
+    except RuntimeError:
+        net.load_state_dict({k[7:]: v for k, v in state_dict.items()})
+    net.eval()
+    return net
+
+
+def make_gen_1_img(new_net, batch_size_fid=1024, integration_steps=100, integration_method="euler", device="cuda:0"):
+    if integration_method != "euler":
+        raise NotImplementedError("only --integration_method euler is built (dopri5 is a 'next' row, SURVEY.md 8f)")
+    device = torch.device(device)
+
+    def gen_1_img(unused_latent):
+        with torch.no_grad():
+            B = int(batch_size_fid)
+            lo, hi = mdist.shard_range(B)
+            x = torch.randn(B, 3, 32, 32, device=device)[lo:hi].contiguous()  # same draw on every rank, rank takes its slice
+            t_span = torch.linspace(0, 1, integration_steps + 1).tolist()
+            _, _, img = new_net.engine(device).cfm_euler(x, t_span, want_u8=True)  # (traj*127.5+128).clip(0,255).to(uint8)
+            return mdist.all_gather_batch(img, B)
+
+    return gen_1_img
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num_channel", type=int, default=128)
+    ap.add_argument("--input_dir", default="./results")
+    ap.add_argument("--model", default="otcfm")
+    ap.add_argument("--integration_steps", type=int, default=100)
+    ap.add_argument("--integration_method", default="euler")
+    ap.add_argument("--step", type=int, default=400000)
+    ap.add_argument("--num_gen", type=int, default=50000)
+    ap.add_argument("--batch_size_fid", type=int, default=1024)
+    a = ap.parse_args(argv)
+    rank, world, local = mdist.init_from_env()
+    device = f"cuda:{local}"
+    net = build_model(a.num_channel, device)
+    path = f"{a.input_dir}/{a.model}/{a.model}_cifar10_weights_step_{a.step}.pt"
+    print("path: ", path)
+    load_checkpoint(net, path)
+    gen = make_gen_1_img(net, a.batch_size_fid, a.integration_steps, a.integration_method, device)
+    try:
+        from cleanfid import fid
+    except ImportError as e:
+        raise SystemExit("cleanfid is not installed (it downloads Inception weights and CIFAR statistics); "
+                         "gen_1_img is ready for fid.compute_fid(gen=gen_1_img, ...) when it is") from e
+    score = fid.compute_fid(gen=gen, dataset_name="cifar10", batch_size=a.batch_size_fid, dataset_res=32, num_gen=a.num_gen,
+                            dataset_split="train", mode="legacy_tensorflow")
+    if rank == 0:
+        print("FID: ", score)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,277 @@
+// extern "C" boundary of libmi355_sampler.so (see include/mi355_sampler.h) and the sampler loops.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "unet_engine.h"
+
+static thread_local std::string g_err;
+void mi355_set_error(const std::string& msg) { g_err = msg; }
+
+namespace {
+inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace
+
+extern "C" {
+
+int mi355_version(void) { return 100; }
+const char* mi355_last_error(void) { return g_err.c_str(); }
+
+int mi355_unet_param_count(const mi355_unet_config* cfg) {
+  if (!cfg) { mi355_set_error("null config"); return -1; }
+  std::vector<ParamInfo> p;
+  int rc = unet_enumerate_params(*cfg, p);
+  return rc ? rc : (int)p.size();
+}
+
+int mi355_unet_param_info(const mi355_unet_config* cfg, int index, char* name, int name_cap, int64_t shape[4], int* ndim) {
+  if (!cfg || !name || !shape || !ndim) { mi355_set_error("null argument"); return -1; }
+  std::vector<ParamInfo> p;
+  if (int rc = unet_enumerate_params(*cfg, p)) return rc;
+  MI355_REQUIRE(index >= 0 && index < (int)p.size(), -1, "param index out of range");
+  MI355_REQUIRE((int)p[index].name.size() + 1 <= name_cap, -1, "name buffer too small");
+  std::strcpy(name, p[index].name.c_str());
+  *ndim = (int)p[index].shape.size();
+  for (int i = 0; i < 4; ++i) shape[i] = i < *ndim ? p[index].shape[i] : 1;
+  return 0;
+}
+
+int64_t mi355_unet_weight_bytes(const mi355_unet_config* cfg) {
+  if (!cfg) { mi355_set_error("null config"); return -1; }
+  return unet_weight_bytes(*cfg);
+}
+
+int mi355_unet_create(const mi355_unet_config* cfg, const float* const* params_host, int n_params, void* dev_weights,
+                      int64_t dev_weights_bytes, void* stream, mi355_unet** out) {
+  if (!cfg) { mi355_set_error("null config"); return -1; }
+  return unet_build(*cfg, params_host, n_params, dev_weights, dev_weights_bytes, S(stream), out);
+}
+
+void mi355_unet_destroy(mi355_unet* net) { delete net; }
+
+int64_t mi355_unet_workspace_bytes(const mi355_unet* net, int batch) {
+  if (!net || batch <= 0) { mi355_set_error("bad argument"); return -1; }
+  // + sampler scratch: t[B], eps/v [B,Cout,H,W], none_like [B,Cin,H,W]
+  const size_t hw = (size_t)net->cfg.image_size * net->cfg.image_size;
+  const size_t scratch = al256((size_t)batch * 4) + 2 * al256((size_t)batch * 32 * hw * 4);
+  return unet_workspace_bytes(net, batch) + (int64_t)scratch;
+}
+
+int mi355_unet_forward(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels, const float* t,
+                       float* out, int batch, void* workspace, int64_t workspace_bytes, void* stream) {
+  return unet_forward(net, x, x_channels, cond, cond_channels, t, out, batch, workspace, workspace_bytes, S(stream));
+}
+
+int mi355_unet_get_stats(const mi355_unet* net, int batch, mi355_unet_stats* out) {
+  if (!net || !out) { mi355_set_error("null argument"); return -1; }
+  out->launches = net->launches;
+  out->conv_flops = net->conv_flops * batch;
+  out->attn_flops = net->attn_flops * batch;
+  out->act_bytes = net->act_bytes * batch;
+  out->weight_bytes = net->weight_bytes;
+  return 0;
+}
+
+// ---- sampler loops --------------------------------------------------------------------------------
+
+struct Scratch { float* t; float* v; float* none; char* unet_ws; int64_t unet_bytes; };
+static int carve(mi355_unet* net, int B, void* workspace, int64_t workspace_bytes, Scratch& sc) {
+  MI355_REQUIRE(net && workspace, -1, "null argument");
+  MI355_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, -1, "workspace must be 256-byte aligned");
+  MI355_REQUIRE(workspace_bytes >= mi355_unet_workspace_bytes(net, B), -2, "workspace too small");
+  const size_t hw = (size_t)net->cfg.image_size * net->cfg.image_size;
+  char* p = reinterpret_cast<char*>(workspace);
+  sc.t = reinterpret_cast<float*>(p); p += al256((size_t)B * 4);
+  sc.v = reinterpret_cast<float*>(p); p += al256((size_t)B * 32 * hw * 4);
+  sc.none = reinterpret_cast<float*>(p); p += al256((size_t)B * 32 * hw * 4);
+  sc.unet_ws = p;
+  sc.unet_bytes = workspace_bytes - (p - reinterpret_cast<char*>(workspace));
+  return 0;
+}
+
+int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const float* cond, int cond_channels,
+                           const float* t_span_host, int n_t, float* traj, uint8_t* u8_out, int batch, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+  MI355_REQUIRE(net && x && t_span_host && n_t >= 1, -1, "cfm_euler_sample: bad argument");
+  MI355_REQUIRE(x_channels == net->cfg.out_channels, -2, "cfm_euler_sample: the vector field must have the state's channel count");
+  Scratch sc;
+  if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
+  hipStream_t s = S(stream);
+  const int64_t n = (int64_t)batch * x_channels * net->cfg.image_size * net->cfg.image_size;
+  if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  for (int k = 0; k + 1 < n_t; ++k) {
+    const float t = t_span_host[k], dt = t_span_host[k + 1] - t_span_host[k];
+    int rc;
+    if ((rc = fill_launch(sc.t, t, batch, s))) return rc;
+    if ((rc = unet_forward(net, x, x_channels, cond, cond_channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s))) return rc;
+    if ((rc = euler_step_launch(x, sc.v, dt, n, s))) return rc;
+    if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * n, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  }
+  if (u8_out) return quantize_u8_launch(x, u8_out, n, s);
+  return 0;
+}
+
+int mi355_ddpm_sample(mi355_unet* net, float* x, int channels, const float* cond, const mi355_ddpm_tables* tb,
+                      const mi355_ddpm_options* opt, const float* noise, int64_t n_noise_draws, int batch, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  MI355_REQUIRE(net && x && tb && opt, -1, "ddpm_sample: null argument");
+  MI355_REQUIRE(channels == net->cfg.out_channels, -2, "ddpm_sample: eps model must output the state's channel count");
+  const int mode = opt->mode, Ns = tb->Ns;
+  const bool amortized = net->cfg.in_channels == 2 * channels;
+  MI355_REQUIRE(amortized || net->cfg.in_channels == channels, -2, "ddpm_sample: network in_channels must be C or 2C");
+  MI355_REQUIRE(mode != MI355_DDPM_REPLACEMENT || (!amortized && cond), -2, "ddpm_sample: replacement needs an unconditional net and a condition");
+  MI355_REQUIRE(mode != MI355_DDPM_AMORTIZED || (amortized && cond), -2, "ddpm_sample: amortized needs a 2C-input net and a condition");
+  Scratch sc;
+  if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
+  hipStream_t s = S(stream);
+  const int64_t n = (int64_t)batch * channels * net->cfg.image_size * net->cfg.image_size;
+  const int64_t n_al = (n + 3) / 4 * 4;
+  int rc;
+  if (amortized && (rc = fill_launch(sc.none, opt->none_value, n, s))) return rc;
+  // the net's condition input on predictor steps / on corrector steps (the reference's corrector calls
+  // x0_model without the condition, sampling.py:116 -> none_like)
+  const float* cond_pred = !amortized ? nullptr : ((mode == MI355_DDPM_AMORTIZED || (mode == MI355_DDIM && cond)) ? cond : sc.none);
+  const float* cond_corr = amortized ? sc.none : nullptr;
+  int64_t draw = 0;
+  auto next_noise = [&](const float*& zptr, int& philox, uint64_t& off) -> int {
+    if (noise) {
+      MI355_REQUIRE(draw < n_noise_draws, -2, "ddpm_sample: injected noise exhausted");
+      zptr = noise + (size_t)draw * n; philox = 0; off = 0;
+    } else { zptr = nullptr; philox = 1; off = (uint64_t)draw * (uint64_t)n_al; }
+    ++draw;
+    return 0;
+  };
+  for (int i = Ns - 1; i >= 0; --i) {
+    const float tval = (float)i / (float)Ns;  // eps_model(xi, i) = network(xi, 1.0*i/Ns)  loss_functions.py:18-19
+    if (mode == MI355_DDPM_REPLACEMENT && i < (int)(Ns * opt->start_fraction)) {
+      const float* z = nullptr; int ph = 0; uint64_t off = 0;
+      if (opt->noise_condition && (rc = next_noise(z, ph, off))) return rc;
+      if ((rc = replace_mask_launch(x, cond, z, opt->pad_value, opt->noise_condition, tb->sqrt_alphas_cumprod[i],
+                                    tb->sqrt_one_minus_alphas_cumprod[i], ph, opt->seed, off, n, s))) return rc;
+    }
+    if ((rc = fill_launch(sc.t, tval, batch, s))) return rc;
+    if ((rc = unet_forward(net, x, channels, cond_pred, channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s))) return rc;
+    if (mode == MI355_DDIM) {
+      if ((rc = ddim_step_launch(x, sc.v, tb->sqrt_recip_alphas_cumprod[i], tb->sqrt_recipm1_alphas_cumprod[i],
+                                 tb->alphas_cumprod_prev[i], n, s))) return rc;
+      continue;
+    }
+    const float* z = nullptr; int ph = 0; uint64_t off = 0;
+    if (i > 0 && (rc = next_noise(z, ph, off))) return rc;
+    const float sigma = expf(0.5f * tb->posterior_log_variance_clipped[i]);
+    if ((rc = ddpm_step_launch(x, sc.v, z, tb->sqrt_recip_alphas_cumprod[i], tb->sqrt_recipm1_alphas_cumprod[i],
+                               tb->posterior_mean_coef1[i], tb->posterior_mean_coef2[i], sigma, ph, opt->seed, off, n, s))) return rc;
+    for (int c = 0; c < opt->n_corrector; ++c) {
+      if ((rc = unet_forward(net, x, channels, cond_corr, channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s))) return rc;
+      const float* z2 = nullptr; int ph2 = 0; uint64_t off2 = 0;
+      if ((rc = next_noise(z2, ph2, off2))) return rc;
+      const float dt = (opt->tmax - opt->tmin) / (float)Ns;
+      if ((rc = corrector_step_launch(x, sc.v, z2, tb->sqrt_recip_alphas_cumprod[i], tb->sqrt_recipm1_alphas_cumprod[i],
+                                      tb->recip_sqrt_m1_alphas_cumprod[i], dt, opt->delta, ph2, opt->seed, off2, n, s))) return rc;
+    }
+  }
+  return clip_launch(x, -1.f, 1.f, n, s);
+}
+
+// ---- single ops -------------------------------------------------------------------------------------
+
+int mi355_timestep_embedding(const float* t, int batch, int dim, float max_period, float* out, void* stream) {
+  MI355_REQUIRE(t && out && batch > 0 && dim > 0, -1, "timestep_embedding: bad argument");
+  return timestep_embedding_launch(t, batch, dim, max_period, out, S(stream));
+}
+int mi355_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int batch, int channels, int hw, int groups,
+                    float eps, int silu, void* stream) {
+  MI355_REQUIRE(x && gamma && beta && y, -1, "groupnorm: null argument");
+  return groupnorm_nchw_launch(x, gamma, beta, y, batch, channels, hw, groups, eps, silu, S(stream));
+}
+int mi355_euler_step(float* x, const float* v, float dt, int64_t n, void* stream) { return euler_step_launch(x, v, dt, n, S(stream)); }
+int mi355_ddpm_step(float* x, const float* eps, const float* z, float c_recip, float c_recipm1, float coef1, float coef2,
+                    float sigma, int use_philox, uint64_t seed, uint64_t offset, int64_t n, void* stream) {
+  return ddpm_step_launch(x, eps, z, c_recip, c_recipm1, coef1, coef2, sigma, use_philox, seed, offset, n, S(stream));
+}
+int mi355_corrector_step(float* x, const float* eps, const float* z, float c_recip, float c_recipm1, float recip_sqrt_m1, float dt,
+                         float delta, int use_philox, uint64_t seed, uint64_t offset, int64_t n, void* stream) {
+  return corrector_step_launch(x, eps, z, c_recip, c_recipm1, recip_sqrt_m1, dt, delta, use_philox, seed, offset, n, S(stream));
+}
+int mi355_ddim_step(float* x, const float* eps, float c_recip, float c_recipm1, float acp_prev, int64_t n, void* stream) {
+  return ddim_step_launch(x, eps, c_recip, c_recipm1, acp_prev, n, S(stream));
+}
+int mi355_replace_mask(float* x, const float* cond, const float* z, float pad_value, int noisy, float sa, float sb, int use_philox,
+                       uint64_t seed, uint64_t offset, int64_t n, void* stream) {
+  return replace_mask_launch(x, cond, z, pad_value, noisy, sa, sb, use_philox, seed, offset, n, S(stream));
+}
+int mi355_clip(float* x, float lo, float hi, int64_t n, void* stream) { return clip_launch(x, lo, hi, n, S(stream)); }
+int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream) { return quantize_u8_launch(x, out, n, S(stream)); }
+int mi355_to_unit_range(const float* x, float* out, int64_t n, void* stream) { return to_unit_range_launch(x, out, n, S(stream)); }
+int mi355_randn(float* out, uint64_t seed, uint64_t offset, int64_t n, void* stream) { return randn_launch(out, seed, offset, n, S(stream)); }
+
+int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw) {
+  const size_t c = (size_t)max_channels + 32;
+  return (int64_t)(2 * al256((size_t)batch * hw * 4 * c * 4) + al256(c * c * 9 * 4 * 2) + 4 * al256((size_t)batch * c * 4) + (1 << 20));
+}
+
+int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, float* y, int batch, int cin, int h, int w, int cout,
+                 int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu, int dtype,
+                 void* workspace, int64_t workspace_bytes, void* stream) {
+  MI355_REQUIRE(x && w_host && y && workspace, -1, "conv2d: null argument");
+  MI355_REQUIRE(dtype == 0 || dtype == 1, -1, "conv2d: bad dtype");
+  MI355_REQUIRE(stride == 1 || stride == 2, -1, "conv2d: stride must be 1 or 2");
+  MI355_REQUIRE(!(stride == 2 && resample), -1, "conv2d: stride 2 cannot be combined with resampling");
+  hipStream_t s = S(stream);
+  const int CH = dtype == 0 ? 16 : 32, esz = dtype == 0 ? 4 : 2;
+  const int cpad = (cin + CH - 1) / CH * CH;
+  ConvDesc d; d.dtype = dtype; d.N = batch; d.Hs = h; d.Ws = w; d.C0 = cpad; d.ks = ksize; d.Cout = cout;
+  d.mode = stride == 2 ? CONV_STRIDE2 : (resample == 2 ? CONV_UP2 : (resample == 3 ? CONV_POOL2 : CONV_UNIT));
+  const ConvGeom g = conv_geometry(d);
+  char* p = reinterpret_cast<char*>(workspace);
+  char* end = p + workspace_bytes;
+  void* xin = p; p += al256((size_t)batch * h * w * cpad * esz);
+  void* wdev = p; const size_t wbytes = conv_packed_weight_bytes(dtype, cout, cin, ksize); p += al256(wbytes);
+  float* bdev = reinterpret_cast<float*>(p); p += al256((size_t)cout * 4);
+  float* ga = reinterpret_cast<float*>(p); p += al256((size_t)batch * cpad * 4);
+  float* gb = reinterpret_cast<float*>(p); p += al256((size_t)batch * cpad * 4);
+  float* gpad = reinterpret_cast<float*>(p); p += 2 * al256((size_t)cpad * 4);
+  void* yout = p; p += al256((size_t)batch * g.Ho * g.Wo * cout * esz);
+  MI355_REQUIRE(p <= end, -2, "conv2d: workspace too small");
+  int rc;
+  if ((rc = pack_nhwc_launch(dtype, x, cin, nullptr, 0, batch, h * w, cpad, xin, s))) return rc;
+  std::vector<char> packed(wbytes);
+  conv_pack_weights(dtype, w_host, cout, cin, ksize, packed.data());
+  MI355_CHECK_HIP(hipMemcpyAsync(wdev, packed.data(), wbytes, hipMemcpyHostToDevice, s));
+  if (bias_host) MI355_CHECK_HIP(hipMemcpyAsync(bdev, bias_host, (size_t)cout * 4, hipMemcpyHostToDevice, s));
+  if (gn_gamma) {
+    MI355_REQUIRE(cin % 32 == 0, -2, "conv2d: the GroupNorm32 prologue needs cin % 32 == 0");
+    GnDesc gd; gd.dtype = dtype; gd.src0 = xin; gd.C0 = cpad; gd.N = batch; gd.HW = h * w; gd.gamma = gn_gamma; gd.beta = gn_beta;
+    gd.a = ga; gd.b = gb;
+    (void)gpad;
+    if ((rc = gn_affine_launch(gd, s))) return rc;
+    d.pro_a = ga; d.pro_b = gb; d.pro_silu = gn_silu;
+  }
+  d.src0 = xin; d.w = wdev; d.bias = bias_host ? bdev : nullptr;
+  const bool nhwc = cout % 4 == 0;
+  d.out_mode = nhwc ? OUT_NHWC : OUT_NCHW_F32;
+  d.out = nhwc ? yout : (void*)y;
+  if ((rc = conv_launch(d, s))) return rc;
+  if (nhwc && (rc = unpack_nchw_launch(dtype, yout, batch, g.Ho * g.Wo, cout, y, s))) return rc;
+  MI355_CHECK_HIP(hipStreamSynchronize(s));  // `packed` is a temporary host buffer
+  return 0;
+}
+
+int mi355_qkv_attention(const float* qkv, float* out, int batch, int heads, int head_channels, int length, int new_order, int dtype,
+                        void* workspace, int64_t workspace_bytes, void* stream) {
+  MI355_REQUIRE(qkv && out && workspace, -1, "qkv_attention: null argument");
+  hipStream_t s = S(stream);
+  const int esz = dtype == 0 ? 4 : 2, C = heads * head_channels;
+  char* p = reinterpret_cast<char*>(workspace);
+  void* qin = p; p += al256((size_t)batch * length * 3 * C * esz);
+  void* o = p; p += al256((size_t)batch * length * C * esz);
+  MI355_REQUIRE(p <= reinterpret_cast<char*>(workspace) + workspace_bytes, -2, "qkv_attention: workspace too small");
+  int rc;
+  if ((rc = pack_nhwc_launch(dtype, qkv, 3 * C, nullptr, 0, batch, length, 3 * C, qin, s))) return rc;
+  AttnDesc a; a.dtype = dtype; a.qkv = qin; a.out = o; a.N = batch; a.T = length; a.heads = heads; a.ch = head_channels; a.new_order = new_order;
+  if ((rc = attention_launch(a, s))) return rc;
+  return unpack_nchw_launch(dtype, o, batch, length, C, out, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// Shared device/host helpers for libmi355_sampler (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstring>
+#include <string>
+
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// One "K chunk" is 64 bytes of channels per pixel in both precisions, so every LDS image (rows of
+// 64 B split into four 16-B fragments) is byte-identical between the fp32 and the bf16 build of a
+// kernel; only the number of channels per chunk differs.
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int CHUNK = 16;  // channels per 64-B chunk
+  static constexpr int VEC = 4;     // channels per 16-B fragment
+  static constexpr int DTYPE = 0;
+};
+template <> struct Elem<bf16> {
+  static constexpr int CHUNK = 32;
+  static constexpr int VEC = 8;
+  static constexpr int DTYPE = 1;
+};
+
+// 16-B fragment <-> float conversions
+__device__ __forceinline__ void frag_to_float(const u32x4& v, float (&f)[4], float) {
+  f[0] = __builtin_bit_cast(float, v[0]); f[1] = __builtin_bit_cast(float, v[1]);
+  f[2] = __builtin_bit_cast(float, v[2]); f[3] = __builtin_bit_cast(float, v[3]);
+}
+__device__ __forceinline__ void frag_to_float(const u32x4& v, float (&f)[8], bf16) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+    f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 float_to_frag(const float (&f)[4], float) {
+  u32x4 v;
+  v[0] = __builtin_bit_cast(uint32_t, f[0]); v[1] = __builtin_bit_cast(uint32_t, f[1]);
+  v[2] = __builtin_bit_cast(uint32_t, f[2]); v[3] = __builtin_bit_cast(uint32_t, f[3]);
+  return v;
+}
+__device__ __forceinline__ u32x4 float_to_frag(const float (&f)[8], bf16) {
+  bf16x8 b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b[i] = (bf16)f[i];  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+  return __builtin_bit_cast(u32x4, b);
+}
+
+// one 16-B x 16-B fragment pair -> 16x16 f32 accumulator.
+//   bf16: one v_mfma_f32_16x16x32_bf16 (K = 32 across the 4 lane quads)
+//   f32 : four v_mfma_f32_16x16x4_f32 (K = 16), exact f32 (k-ordered fmaf chain)
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, bf16) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, float) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[i]), __builtin_bit_cast(float, b[i]), acc, 0, 0, 0);
+}
+
+template <bool FAST> __device__ __forceinline__ float silu_f(float v) {
+  if (FAST) return __fdividef(v, 1.0f + __expf(-v));
+  return v / (1.0f + expf(-v));
+}
+
+// torch.clip semantics: NaN propagates (fminf/fmaxf would drop it; DDPM(Ns<=20) relies on NaN).
+__device__ __forceinline__ float clip_nan(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+static inline int ilog2_ceil(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// ---- error plumbing (host) ----------------------------------------------------------------------
+void mi355_set_error(const std::string& msg);
+#define MI355_CHECK_HIP(expr)                                                                       \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      mi355_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+      return -3;                                                                                    \
+    }                                                                                               \
+  } while (0)
+#define MI355_REQUIRE(cond, code, msg)                                                              \
+  do {                                                                                              \
+    if (!(cond)) {                                                                                  \
+      mi355_set_error(std::string(msg) + " [" #cond "]");                                         \
+      return code;                                                                                  \
+    }                                                                                               \
+  } while (0)

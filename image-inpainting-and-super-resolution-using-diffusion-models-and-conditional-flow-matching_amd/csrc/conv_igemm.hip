@@ -1,0 +1,422 @@
+// Implicit-GEMM convolution (3x3 / 1x1, stride 1 / 2, fused nearest-up / avg-pool gather) on MFMA.
+//
+// Replaces, for inference, every conv2d / conv1d(1) of the reference U-Net together with the ops
+// the reference runs around it as separate eager kernels (AD/image_diffusion/unet.py):
+//   GroupNorm32-apply + SiLU (+ FiLM)   unet.py:283-286,306-311,343-350  -> prologue while staging
+//   F.interpolate(nearest x2) / AvgPool unet.py:209,236,332-337          -> gather mode
+//   th.cat([h, hs.pop()], 1)            unet.py:725                      -> two-source K loop
+//   h + emb_out, skip + h, x + proj     unet.py:349,351,401              -> epilogue
+//
+// GEMM view: M = output pixels (BM per workgroup: a rectangle of one image, or several whole small
+// images), N = output channels (BN per workgroup), K = taps x input channels, walked as
+// (64-byte channel chunk) x (kernel row) x (kernel column).  Per chunk the haloed input patch is
+// staged ONCE into LDS ([patch pixel][64 B], rows padded to 96 B so the 16-lane ds_read_b128 groups
+// of every tap shift are bank-conflict free) and re-read by all 9 taps at shifted row addresses;
+// weights arrive pre-tiled / pre-swizzled from the host packer so staging them is a linear copy.
+// 4 waves per workgroup, v_mfma_f32_16x16x32_bf16 (or v_mfma_f32_16x16x4_f32 in the fp32 build).
+#include "ops.h"
+
+namespace {
+
+constexpr int PROW = 96;   // bytes per patch pixel row in LDS (64 data + 32 pad)
+constexpr int NTHREADS = 256;
+
+struct ConvKArgs {
+  const void* src0; const void* src1;
+  int C0, C1, Cin, nchunks;
+  int N, Hs, Ws, Hc, Wc, Ho, Wo;
+  int mode, ks, pad, stride;
+  const float* pro_a; const float* pro_b; int pro_silu;
+  const void* w; const float* bias; int Cout;
+  const float* emb; int emb_stride;
+  const void* res; int res_mode; int Hr, Wr;
+  void* out; int out_mode;
+  int lvw, lth, G, PW, PH, NP, tiles_x, tiles_y;
+  int patch_bytes;
+};
+
+template <typename T, bool FAST>
+__device__ __forceinline__ void load_transform(float (&f)[Elem<T>::VEC], const T* ptr, const float* a, const float* b,
+                                               int silu) {
+  constexpr int V = Elem<T>::VEC;
+  u32x4 raw = *reinterpret_cast<const u32x4*>(ptr);
+  frag_to_float(raw, f, T());
+  if (a) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float v = a[j] * f[j] + b[j];
+      f[j] = silu ? silu_f<FAST>(v) : v;
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(ConvKArgs p) {
+  using E = Elem<T>;
+  constexpr int V = E::VEC, CHUNK = E::CHUNK;
+  constexpr bool FAST = (E::DTYPE == 1);
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int WTILE = BN * 64;  // bytes of one (chunk, tap) weight tile
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  char* wlds = smem + p.patch_bytes;
+  int* srctab = reinterpret_cast<int*>(wlds + 3 * WTILE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  const int nt = blockIdx.y;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int ng = blockIdx.x / tpi, rem = blockIdx.x - ng * tpi;
+  const int tyi = rem / p.tiles_x, txi = rem - tyi * p.tiles_x;
+  const int n0 = ng * p.G, y0 = tyi << p.lth, x0 = txi << p.lvw;
+  const int VWm = (1 << p.lvw) - 1, THm = (1 << p.lth) - 1;
+  const int pimg = p.PH * p.PW;
+
+  // ---- patch pixel -> source pixel table (once per workgroup) ----
+  {
+    const int cy0 = y0 * p.stride - p.pad, cx0 = x0 * p.stride - p.pad;
+    for (int i = tid; i < p.NP; i += NTHREADS) {
+      const int g = i / pimg, r = i - g * pimg;
+      const int py = r / p.PW, px = r - py * p.PW;
+      const int n = n0 + g, cy = cy0 + py, cx = cx0 + px;
+      int s = -1;
+      if (n < p.N && cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
+        if (p.mode == CONV_UP2) s = (n * p.Hs + (cy >> 1)) * p.Ws + (cx >> 1);
+        else if (p.mode == CONV_POOL2) s = (n * p.Hs + 2 * cy) * p.Ws + 2 * cx;
+        else s = (n * p.Hs + cy) * p.Ws + cx;
+      }
+      srctab[i] = s;
+    }
+  }
+
+  int arow[MI], brow[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = wm * WTM + mi * 16 + lr;
+    const int tx = m & VWm, ty = (m >> p.lvw) & THm, g = m >> (p.lvw + p.lth);
+    arow[mi] = ((g * p.PH + ty * p.stride) * p.PW + tx * p.stride) * PROW + lq * 16;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = wn * WTN + ni * 16 + lr;
+    brow[ni] = row * 64 + 16 * (lq ^ ((row >> 1) & 3));
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();
+
+  const int ks = p.ks, ntaps = ks * ks;
+  const char* wbase = reinterpret_cast<const char*>(p.w) + (size_t)nt * p.nchunks * ntaps * WTILE;
+  const int nfrag = p.NP * 4;
+
+  for (int c = 0; c < p.nchunks; ++c) {
+    // ---------------- stage the input patch of this channel chunk (prologue fused) ----------------
+    {
+      const int cb = c * CHUNK;
+      const bool from0 = cb < p.C0;
+      const T* sp = from0 ? reinterpret_cast<const T*>(p.src0) + cb : reinterpret_cast<const T*>(p.src1) + (cb - p.C0);
+      const int Cs = from0 ? p.C0 : p.C1;
+      for (int e = tid; e < nfrag; e += NTHREADS) {
+        const int pix = e >> 2, q = e & 3;
+        const int s = srctab[pix];
+        u32x4 outv = u32x4{0u, 0u, 0u, 0u};
+        if (s >= 0) {
+          const T* ptr = sp + (size_t)s * Cs + q * V;
+          if (p.pro_a == nullptr && p.mode != CONV_POOL2) {
+            outv = *reinterpret_cast<const u32x4*>(ptr);
+          } else {
+            const float* pa = nullptr; const float* pb = nullptr;
+            if (p.pro_a) {
+              const int n = n0 + (p.G > 1 ? pix / pimg : 0);
+              pa = p.pro_a + (size_t)n * p.Cin + cb + q * V;
+              pb = p.pro_b + (size_t)n * p.Cin + cb + q * V;
+            }
+            float f[V];
+            if (p.mode == CONV_POOL2) {
+              float t0[V], t1[V], t2[V], t3[V];
+              load_transform<T, FAST>(t0, ptr, pa, pb, p.pro_silu);
+              load_transform<T, FAST>(t1, ptr + Cs, pa, pb, p.pro_silu);
+              load_transform<T, FAST>(t2, ptr + (size_t)p.Ws * Cs, pa, pb, p.pro_silu);
+              load_transform<T, FAST>(t3, ptr + (size_t)(p.Ws + 1) * Cs, pa, pb, p.pro_silu);
+#pragma unroll
+              for (int j = 0; j < V; ++j) f[j] = 0.25f * ((t0[j] + t1[j]) + (t2[j] + t3[j]));
+            } else {
+              load_transform<T, FAST>(f, ptr, pa, pb, p.pro_silu);
+            }
+            outv = float_to_frag(f, T());
+          }
+        }
+        *reinterpret_cast<u32x4*>(patch + pix * PROW + q * 16) = outv;
+      }
+    }
+    // ---------------- kernel rows: stage ks weight tiles, MFMA over ks taps ----------------
+    for (int ky = 0; ky < ks; ++ky) {
+      const char* wsrc = wbase + ((size_t)c * ntaps + ky * ks) * WTILE;
+      for (int i = tid * 16; i < ks * WTILE; i += NTHREADS * 16)
+        *reinterpret_cast<u32x4*>(wlds + i) = *reinterpret_cast<const u32x4*>(wsrc + i);
+      __syncthreads();
+      for (int kx = 0; kx < ks; ++kx) {
+        const int tapoff = (ky * p.PW + kx) * PROW;
+        u32x4 a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(patch + arow[mi] + tapoff);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(wlds + kx * WTILE + brow[ni]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], a[mi], b[ni], T());
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---------------- epilogue: acc -> LDS (wave-private fp32 tile) -> coalesced rows ----------------
+  constexpr int RP = WTM >= 32 ? 32 : 16;   // rows per pass
+  constexpr int MPP = RP / 16;              // mi tiles per pass
+  constexpr int SST = WTN + 4;              // padded row stride (floats): conflict-free 4-row-apart writes
+  float* stage = reinterpret_cast<float*>(smem) + wave * (RP * SST);
+  const int co_w = nt * BN + wn * WTN;      // first output channel of this wave
+#pragma unroll
+  for (int pass = 0; pass < WTM / RP; ++pass) {
+#pragma unroll
+    for (int ml = 0; ml < MPP; ++ml)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[(ml * 16 + lq * 4 + r) * SST + ni * 16 + lr] = acc[pass * MPP + ml][ni][r];
+    __syncthreads();
+    if (p.out_mode == OUT_NHWC) {
+      constexpr int LPR = WTN / 4;          // lanes per row (4 channels each)
+      constexpr int RPI = 64 / LPR;         // rows per wave iteration
+      const int c4 = (lane % LPR) * 4, r_in = lane / LPR;
+      const int co = co_w + c4;
+#pragma unroll
+      for (int it = 0; it < RP / RPI; ++it) {
+        const int r = it * RPI + r_in;
+        const int m = wm * WTM + pass * RP + r;
+        const int tx = m & VWm, ty = (m >> p.lvw) & THm, g = m >> (p.lvw + p.lth);
+        const int n = n0 + g, y = y0 + ty, x = x0 + tx;
+        if (n < p.N && y < p.Ho && x < p.Wo && co < p.Cout) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * SST + c4);
+          float o[4] = {v[0], v[1], v[2], v[3]};
+          if (p.bias) {
+            f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += bv[j];
+          }
+          if (p.emb) {
+            f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)n * p.emb_stride + co);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += ev[j];
+          }
+          if (p.res_mode != RES_NONE) {
+            const T* rp = reinterpret_cast<const T*>(p.res);
+            auto ld4 = [&](size_t pixel, float (&d)[4]) {
+              const T* q = rp + pixel * p.Cout + co;
+              if constexpr (E::DTYPE == 0) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(q);
+                d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3];
+              } else {
+                bf16x4 t = *reinterpret_cast<const bf16x4*>(q);
+                d[0] = (float)t[0]; d[1] = (float)t[1]; d[2] = (float)t[2]; d[3] = (float)t[3];
+              }
+            };
+            float rv[4];
+            if (p.res_mode == RES_SAME) {
+              ld4(((size_t)n * p.Hr + y) * p.Wr + x, rv);
+            } else if (p.res_mode == RES_UP2) {
+              ld4(((size_t)n * p.Hr + (y >> 1)) * p.Wr + (x >> 1), rv);
+            } else {
+              float r0[4], r1[4], r2[4], r3[4];
+              const size_t b0 = ((size_t)n * p.Hr + 2 * y) * p.Wr + 2 * x;
+              ld4(b0, r0); ld4(b0 + 1, r1); ld4(b0 + p.Wr, r2); ld4(b0 + p.Wr + 1, r3);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) rv[j] = 0.25f * ((r0[j] + r1[j]) + (r2[j] + r3[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += rv[j];
+          }
+          T* op = reinterpret_cast<T*>(p.out) + (((size_t)n * p.Ho + y) * p.Wo + x) * p.Cout + co;
+          if constexpr (E::DTYPE == 0) {
+            *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
+          } else {
+            bf16x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (bf16)o[j];
+            *reinterpret_cast<bf16x4*>(op) = t;
+          }
+        }
+      }
+    } else {  // OUT_NCHW_F32: few output channels (final conv), pixel-contiguous fp32 stores
+      const int ncol = min(WTN, p.Cout - co_w);
+      for (int idx = lane; idx < RP * ncol; idx += 64) {
+        const int r = idx % RP, cc = idx / RP;
+        const int m = wm * WTM + pass * RP + r;
+        const int tx = m & VWm, ty = (m >> p.lvw) & THm, g = m >> (p.lvw + p.lth);
+        const int n = n0 + g, y = y0 + ty, x = x0 + tx;
+        if (n < p.N && y < p.Ho && x < p.Wo) {
+          const int co = co_w + cc;
+          float v = stage[r * SST + cc] + (p.bias ? p.bias[co] : 0.f);
+          reinterpret_cast<float*>(p.out)[(((size_t)n * p.Cout + co) * p.Ho + y) * p.Wo + x] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct TileCfg { int BM, BN; };
+
+template <typename T, int BM, int BN, int WM, int WN>
+void launch_t(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), grid, dim3(NTHREADS), lds, s, a);
+}
+
+template <typename T>
+int launch_cfg(const ConvKArgs& a, int BM, int BN, dim3 grid, size_t lds, hipStream_t s) {
+  if (BM == 128 && BN == 128) launch_t<T, 128, 128, 2, 2>(a, grid, lds, s);
+  else if (BM == 128 && BN == 64) launch_t<T, 128, 64, 2, 2>(a, grid, lds, s);
+  else if (BM == 128 && BN == 32) launch_t<T, 128, 32, 4, 1>(a, grid, lds, s);
+  else if (BM == 64 && BN == 128) launch_t<T, 64, 128, 2, 2>(a, grid, lds, s);
+  else if (BM == 64 && BN == 64) launch_t<T, 64, 64, 2, 2>(a, grid, lds, s);
+  else if (BM == 64 && BN == 32) launch_t<T, 64, 32, 4, 1>(a, grid, lds, s);
+  else { mi355_set_error("conv: unsupported tile"); return -4; }
+  return 0;
+}
+
+struct Geo {
+  int Hc, Wc, Ho, Wo, BM, BN, lvw, lth, G, PW, PH, NP, tiles_x, tiles_y, groups, pad, stride, patch_bytes;
+  size_t lds;
+};
+
+int compute_geo(const ConvDesc& d, Geo& g) {
+  g.pad = d.ks / 2;
+  g.stride = d.mode == CONV_STRIDE2 ? 2 : 1;
+  if (d.mode == CONV_UP2) { g.Hc = d.Hs * 2; g.Wc = d.Ws * 2; }
+  else if (d.mode == CONV_POOL2) { g.Hc = d.Hs / 2; g.Wc = d.Ws / 2; }
+  else { g.Hc = d.Hs; g.Wc = d.Ws; }
+  if (d.mode == CONV_STRIDE2) { g.Ho = (g.Hc + 2 * g.pad - d.ks) / 2 + 1; g.Wo = (g.Wc + 2 * g.pad - d.ks) / 2 + 1; }
+  else { g.Ho = g.Hc; g.Wo = g.Wc; }
+  g.BN = conv_tile_n(d.Cout);
+  const long M = (long)d.N * g.Ho * g.Wo;
+  const long tiles128 = ((M + 127) / 128) * ((d.Cout + g.BN - 1) / g.BN);
+  g.BM = tiles128 >= 512 ? 128 : 64;
+  const int lw = ilog2_ceil(g.Wo);
+  g.lvw = (1 << lw) > g.BM ? ilog2_ceil(g.BM) : lw;
+  const int VW = 1 << g.lvw;
+  const int thfull = g.BM / VW;
+  if (g.Ho >= thfull) { g.lth = ilog2_ceil(thfull); g.G = 1; }
+  else { g.lth = ilog2_ceil(g.Ho); g.G = thfull >> g.lth; }
+  const int THp = 1 << g.lth;
+  g.tiles_x = (g.Wo + VW - 1) / VW;
+  g.tiles_y = (g.Ho + THp - 1) / THp;
+  g.groups = (d.N + g.G - 1) / g.G;
+  if (g.stride == 2) { g.PW = 2 * VW + 1; g.PH = 2 * THp + 1; }
+  else { g.PW = VW + 2 * g.pad; g.PH = THp + 2 * g.pad; }
+  g.NP = g.G * g.PH * g.PW;
+  g.patch_bytes = ((g.NP * PROW + 15) / 16) * 16;
+  size_t main_lds = (size_t)g.patch_bytes + 3 * (size_t)g.BN * 64 + (size_t)g.NP * 4;
+  const int WN = g.BN == 32 ? 1 : 2, WM = 4 / WN;
+  const int WTM = g.BM / WM, WTN = g.BN / WN;
+  const int RP = WTM >= 32 ? 32 : 16;
+  size_t epi_lds = (size_t)4 * RP * (WTN + 4) * 4;
+  g.lds = ((main_lds > epi_lds ? main_lds : epi_lds) + 15) / 16 * 16;
+  return 0;
+}
+
+}  // namespace
+
+int conv_tile_n(int Cout) {
+  if (Cout % 128 == 0) return 128;
+  if (Cout % 64 == 0) return 64;
+  return 32;
+}
+
+static inline int chunk_of(int dtype) { return dtype == 0 ? 16 : 32; }
+
+size_t conv_packed_weight_bytes(int dtype, int Cout, int Cin, int ks) {
+  const int BN = conv_tile_n(Cout), CH = chunk_of(dtype);
+  const size_t nt = (Cout + BN - 1) / BN, nc = (Cin + CH - 1) / CH;
+  return nt * nc * ks * ks * (size_t)BN * 64;
+}
+
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+void conv_pack_weights(int dtype, const float* w, int Cout, int Cin, int ks, void* dst) {
+  const int BN = conv_tile_n(Cout), CH = chunk_of(dtype), V = CH / 4, esz = dtype == 0 ? 4 : 2;
+  const int nt = (Cout + BN - 1) / BN, nc = (Cin + CH - 1) / CH, ntaps = ks * ks;
+  char* out = reinterpret_cast<char*>(dst);
+  memset(out, 0, conv_packed_weight_bytes(dtype, Cout, Cin, ks));
+  for (int t = 0; t < nt; ++t)
+    for (int c = 0; c < nc; ++c)
+      for (int tap = 0; tap < ntaps; ++tap) {
+        char* tile = out + (((size_t)t * nc + c) * ntaps + tap) * (size_t)BN * 64;
+        for (int row = 0; row < BN; ++row) {
+          const int co = t * BN + row;
+          if (co >= Cout) break;
+          for (int kl = 0; kl < CH; ++kl) {
+            const int ci = c * CH + kl;
+            if (ci >= Cin) break;
+            const float v = w[((size_t)co * Cin + ci) * ntaps + tap];
+            const int q = kl / V, e = kl % V;
+            char* dstp = tile + row * 64 + 16 * (q ^ ((row >> 1) & 3)) + e * esz;
+            if (dtype == 0) memcpy(dstp, &v, 4);
+            else { uint16_t h = f2bf(v); memcpy(dstp, &h, 2); }
+          }
+        }
+      }
+}
+
+ConvGeom conv_geometry(const ConvDesc& d) {
+  Geo g; compute_geo(d, g);
+  ConvGeom r;
+  r.Ho = g.Ho; r.Wo = g.Wo; r.BM = g.BM; r.BN = g.BN; r.lds_bytes = g.lds;
+  r.grid_m = g.groups * g.tiles_x * g.tiles_y; r.grid_n = (d.Cout + g.BN - 1) / g.BN;
+  return r;
+}
+
+int conv_launch(const ConvDesc& d, hipStream_t stream) {
+  const int CH = chunk_of(d.dtype);
+  const int Cin = d.C0 + d.C1;
+  MI355_REQUIRE(d.ks == 1 || d.ks == 3, -1, "conv: kernel size must be 1 or 3");
+  MI355_REQUIRE(d.C0 % CH == 0 && d.C1 % CH == 0 && Cin > 0, -2, "conv: source channels must be multiples of the 64-byte chunk");
+  MI355_REQUIRE(d.mode == CONV_UNIT || d.ks == 3, -1, "conv: resampling modes need a 3x3 kernel");
+  MI355_REQUIRE(d.out_mode == OUT_NCHW_F32 || d.Cout % 4 == 0, -2, "conv: NHWC output needs Cout % 4 == 0");
+  MI355_REQUIRE(d.mode != CONV_POOL2 || (d.Hs % 2 == 0 && d.Ws % 2 == 0), -2, "conv: avg-pool gather needs even size");
+  Geo g; compute_geo(d, g);
+  MI355_REQUIRE(g.lds <= 160 * 1024, -4, "conv: LDS budget exceeded");
+  ConvKArgs a;
+  a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = Cin / CH;
+  a.N = d.N; a.Hs = d.Hs; a.Ws = d.Ws; a.Hc = g.Hc; a.Wc = g.Wc; a.Ho = g.Ho; a.Wo = g.Wo;
+  a.mode = d.mode; a.ks = d.ks; a.pad = g.pad; a.stride = g.stride;
+  a.pro_a = d.pro_a; a.pro_b = d.pro_b; a.pro_silu = d.pro_silu;
+  a.w = d.w; a.bias = d.bias; a.Cout = d.Cout;
+  a.emb = d.emb; a.emb_stride = d.emb_stride;
+  a.res = d.res; a.res_mode = d.res ? d.res_mode : RES_NONE;
+  a.Hr = d.res_mode == RES_UP2 ? g.Ho / 2 : (d.res_mode == RES_POOL2 ? g.Ho * 2 : g.Ho);
+  a.Wr = d.res_mode == RES_UP2 ? g.Wo / 2 : (d.res_mode == RES_POOL2 ? g.Wo * 2 : g.Wo);
+  a.out = d.out; a.out_mode = d.out_mode;
+  a.lvw = g.lvw; a.lth = g.lth; a.G = g.G; a.PW = g.PW; a.PH = g.PH; a.NP = g.NP;
+  a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.patch_bytes = g.patch_bytes;
+  dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
+  int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, grid, g.lds, stream)
+                        : launch_cfg<bf16>(a, g.BM, g.BN, grid, g.lds, stream);
+  if (rc) return rc;
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}

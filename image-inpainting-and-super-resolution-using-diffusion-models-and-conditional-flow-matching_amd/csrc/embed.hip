@@ -1,0 +1,149 @@
+// Sinusoidal timestep embedding + the small fp32 linears around it, and NCHW<->NHWC boundary packing.
+//
+// Reference: timestep_embedding (AD/image_diffusion/nn.py:97-115), UNetModel.time_embed
+// (unet.py:564-569: Linear, SiLU, Linear) and every ResBlock's emb_layers (unet.py:297-305: SiLU,
+// Linear) - the latter are batched into ONE linear over the concatenated output channels of all
+// ResBlocks per forward.  All fp32 (the reference forces fp32 here, nn.py:111).
+#include "ops.h"
+
+namespace {
+
+__global__ void timestep_embedding_kernel(const float* t, int B, int dim, float max_period, float* out) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * dim) return;
+  const int b = idx / dim, j = idx % dim;
+  float v = 0.f;  // zero pad when dim is odd (nn.py:113-114)
+  if (j < 2 * half) {
+    const int k = j < half ? j : j - half;
+    // freqs = exp(-ln(max_period) * k / half), fp32 like the reference
+    const float freq = expf(-logf(max_period) * (float)k / (float)half);
+    const float arg = t[b] * freq;
+    v = j < half ? cosf(arg) : sinf(arg);
+  }
+  out[idx] = v;
+}
+
+// out[b][j] = bias[j] + sum_k act(in[b][k]) * Wt[k][j].  One thread per (j, 8-row batch slab):
+// Wt reads are coalesced across lanes, in[b][k] is wave-uniform (scalar loads).
+constexpr int LB = 8;
+__global__ void __launch_bounds__(128) linear_kernel(const float* in, const float* Wt, const float* bias, float* out, int B,
+                                                     int K, int J, int in_act, int out_act) {
+  const int j = blockIdx.x * 128 + threadIdx.x;
+  const int b0 = blockIdx.y * LB;
+  if (j >= J) return;
+  float acc[LB];
+#pragma unroll
+  for (int r = 0; r < LB; ++r) acc[r] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float w = Wt[(size_t)k * J + j];
+#pragma unroll
+    for (int r = 0; r < LB; ++r) {
+      const int b = b0 + r;
+      float x = b < B ? in[(size_t)b * K + k] : 0.f;
+      if (in_act) x = silu_f<false>(x);
+      acc[r] = fmaf(x, w, acc[r]);
+    }
+  }
+  const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+  for (int r = 0; r < LB; ++r) {
+    const int b = b0 + r;
+    if (b < B) {
+      float v = acc[r] + bj;
+      out[(size_t)b * J + j] = out_act ? silu_f<false>(v) : v;
+    }
+  }
+}
+
+template <typename T>
+__global__ void pack_nhwc_kernel(const float* x, int Cx, const float* cond, int Cc, int N, int HW, int Cpad, T* out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * HW * Cpad;
+  if (idx >= total) return;
+  const int c = idx % Cpad;
+  const size_t pix = idx / Cpad;
+  const int hw = pix % HW;
+  const size_t n = pix / HW;
+  float v = 0.f;
+  if (c < Cx) v = x[(n * Cx + c) * HW + hw];
+  else if (c < Cx + Cc) v = cond[(n * Cc + (c - Cx)) * HW + hw];
+  out[idx] = (T)v;
+}
+
+template <typename T>
+__global__ void unpack_nchw_kernel(const T* in, int N, int HW, int C, float* out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * HW * C;
+  if (idx >= total) return;
+  const int hw = idx % HW;
+  const size_t r = idx / HW;
+  const int c = r % C;
+  const size_t n = r / C;
+  out[idx] = (float)in[(n * HW + hw) * C + c];
+}
+
+template <typename T>
+__global__ void resample_kernel(const T* in, T* out, int N, int Hs, int Ws, int C, int mode) {
+  const int Ho = mode == CONV_UP2 ? Hs * 2 : Hs / 2, Wo = mode == CONV_UP2 ? Ws * 2 : Ws / 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * Ho * Wo * C;
+  if (idx >= total) return;
+  const int c = idx % C;
+  size_t r = idx / C;
+  const int x = r % Wo; r /= Wo;
+  const int y = r % Ho;
+  const size_t n = r / Ho;
+  float v;
+  if (mode == CONV_UP2) {
+    v = (float)in[((n * Hs + (y >> 1)) * Ws + (x >> 1)) * C + c];
+  } else {
+    const size_t b = ((n * Hs + 2 * y) * Ws + 2 * x) * C + c;
+    v = 0.25f * (((float)in[b] + (float)in[b + C]) + ((float)in[b + (size_t)Ws * C] + (float)in[b + (size_t)Ws * C + C]));
+  }
+  out[idx] = (T)v;
+}
+
+inline dim3 grid1d(size_t total, int block) { return dim3((unsigned)((total + block - 1) / block)); }
+
+}  // namespace
+
+int timestep_embedding_launch(const float* t, int B, int dim, float max_period, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(timestep_embedding_kernel, grid1d((size_t)B * dim, 256), dim3(256), 0, s, t, B, dim, max_period, out);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int linear_launch(const float* in, const float* Wt, const float* bias, float* out, int B, int K, int J, int in_act, int out_act,
+                  hipStream_t s) {
+  dim3 grid((J + 127) / 128, (B + LB - 1) / LB);
+  hipLaunchKernelGGL(linear_kernel, grid, dim3(128), 0, s, in, Wt, bias, out, B, K, J, in_act, out_act);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int pack_nhwc_launch(int dtype, const float* x, int Cx, const float* cond, int Cc, int N, int HW, int Cpad, void* out,
+                     hipStream_t s) {
+  const size_t total = (size_t)N * HW * Cpad;
+  if (dtype == 0) hipLaunchKernelGGL(pack_nhwc_kernel<float>, grid1d(total, 256), dim3(256), 0, s, x, Cx, cond, Cc, N, HW, Cpad, (float*)out);
+  else hipLaunchKernelGGL(pack_nhwc_kernel<bf16>, grid1d(total, 256), dim3(256), 0, s, x, Cx, cond, Cc, N, HW, Cpad, (bf16*)out);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int unpack_nchw_launch(int dtype, const void* in, int N, int HW, int C, float* out, hipStream_t s) {
+  const size_t total = (size_t)N * HW * C;
+  if (dtype == 0) hipLaunchKernelGGL(unpack_nchw_kernel<float>, grid1d(total, 256), dim3(256), 0, s, (const float*)in, N, HW, C, out);
+  else hipLaunchKernelGGL(unpack_nchw_kernel<bf16>, grid1d(total, 256), dim3(256), 0, s, (const bf16*)in, N, HW, C, out);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int resample_launch(int dtype, const void* in, void* out, int N, int Hs, int Ws, int C, int mode, hipStream_t s) {
+  const int Ho = mode == CONV_UP2 ? Hs * 2 : Hs / 2, Wo = mode == CONV_UP2 ? Ws * 2 : Ws / 2;
+  const size_t total = (size_t)N * Ho * Wo * C;
+  if (dtype == 0) hipLaunchKernelGGL(resample_kernel<float>, grid1d(total, 256), dim3(256), 0, s, (const float*)in, (float*)out, N, Hs, Ws, C, mode);
+  else hipLaunchKernelGGL(resample_kernel<bf16>, grid1d(total, 256), dim3(256), 0, s, (const bf16*)in, (bf16*)out, N, Hs, Ws, C, mode);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,149 @@
+// GroupNorm32 statistics -> per-(image, channel) affine  y = a*x + b  consumed by the conv prologue.
+//
+// Reference: GroupNorm32 / normalization (AD/image_diffusion/nn.py:11-13,87-94): nn.GroupNorm(32, C),
+// eps 1e-5, statistics in fp32.  FiLM (use_scale_shift_norm, unet.py:343-347) folds into a, b:
+//   GN(x)*(1+scale)+shift = (a*(1+scale))*x + (b*(1+scale)+shift).
+// The input may be the never-materialised channel concat of two NHWC tensors (unet.py:725).
+//
+// HBM-bound: one pass over the activation, 16 B per lane, a workgroup per image; lanes keep
+// per-channel fp32 partial sums (a 16-B fragment = 4 or 8 fixed channels), reduced through LDS.
+#include "ops.h"
+
+namespace {
+
+struct GnKArgs {
+  const void* src0; const void* src1; int C0, C1;
+  int N, HW, groups; float eps;
+  const float* gamma; const float* beta; const float* film; int film_stride;
+  float* a; float* b;
+};
+
+constexpr int GN_THREADS = 512;
+
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS) gn_affine_kernel(GnKArgs p) {
+  constexpr int V = Elem<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int C = p.C0 + p.C1, CV = C / V;
+  const int ppi = GN_THREADS / CV;  // pixels handled per sweep
+  float* red_s = red;                       // [ppi][C]
+  float* red_q = red + (size_t)ppi * C;     // [ppi][C]
+  float* ch_s = red_q + (size_t)ppi * C;    // [C]
+  float* ch_q = ch_s + C;                   // [C]
+  float* g_mean = ch_q + C;                 // [groups]
+  float* g_rstd = g_mean + p.groups;
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int frag = tid % CV, prow = tid / CV;
+  const int cb = frag * V;
+  float s[V], q[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (prow < ppi) {
+    const bool from0 = cb < p.C0;
+    const T* sp = from0 ? reinterpret_cast<const T*>(p.src0) + cb : reinterpret_cast<const T*>(p.src1) + (cb - p.C0);
+    const int Cs = from0 ? p.C0 : p.C1;
+    sp += (size_t)n * p.HW * Cs;
+    int pix = prow;
+    for (; pix + 3 * ppi < p.HW; pix += 4 * ppi) {  // 4 independent 16-B loads in flight
+      u32x4 r0 = *reinterpret_cast<const u32x4*>(sp + (size_t)pix * Cs);
+      u32x4 r1 = *reinterpret_cast<const u32x4*>(sp + (size_t)(pix + ppi) * Cs);
+      u32x4 r2 = *reinterpret_cast<const u32x4*>(sp + (size_t)(pix + 2 * ppi) * Cs);
+      u32x4 r3 = *reinterpret_cast<const u32x4*>(sp + (size_t)(pix + 3 * ppi) * Cs);
+      float f0[V], f1[V], f2[V], f3[V];
+      frag_to_float(r0, f0, T()); frag_to_float(r1, f1, T()); frag_to_float(r2, f2, T()); frag_to_float(r3, f3, T());
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        s[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
+        q[j] += (f0[j] * f0[j] + f1[j] * f1[j]) + (f2[j] * f2[j] + f3[j] * f3[j]);
+      }
+    }
+    for (; pix < p.HW; pix += ppi) {
+      u32x4 r0 = *reinterpret_cast<const u32x4*>(sp + (size_t)pix * Cs);
+      float f0[V];
+      frag_to_float(r0, f0, T());
+#pragma unroll
+      for (int j = 0; j < V; ++j) { s[j] += f0[j]; q[j] += f0[j] * f0[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red_s[prow * C + cb + j] = s[j]; red_q[prow * C + cb + j] = q[j]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += GN_THREADS) {
+    float ts = 0.f, tq = 0.f;
+    for (int r = 0; r < ppi; ++r) { ts += red_s[r * C + c]; tq += red_q[r * C + c]; }
+    ch_s[c] = ts; ch_q[c] = tq;
+  }
+  __syncthreads();
+  const int cpg = C / p.groups;
+  if (tid < p.groups) {
+    float ts = 0.f, tq = 0.f;
+    for (int j = 0; j < cpg; ++j) { ts += ch_s[tid * cpg + j]; tq += ch_q[tid * cpg + j]; }
+    const float inv = 1.0f / ((float)cpg * (float)p.HW);
+    const float mean = ts * inv;
+    const float var = fmaxf(tq * inv - mean * mean, 0.f);
+    g_mean[tid] = mean;
+    g_rstd[tid] = 1.0f / sqrtf(var + p.eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += GN_THREADS) {
+    const int g = c / cpg;
+    float a = g_rstd[g] * p.gamma[c];
+    float b = p.beta[c] - g_mean[g] * a;
+    if (p.film) {
+      const float sc = 1.0f + p.film[(size_t)n * p.film_stride + c];
+      const float sh = p.film[(size_t)n * p.film_stride + C + c];
+      a *= sc;
+      b = b * sc + sh;
+    }
+    p.a[(size_t)n * C + c] = a;
+    p.b[(size_t)n * C + c] = b;
+  }
+}
+
+// Standalone GroupNorm(+SiLU) on NCHW fp32 (parity-test op; one workgroup per (n, group)).
+__global__ void __launch_bounds__(256) groupnorm_nchw_kernel(const float* x, const float* gamma, const float* beta, float* y,
+                                                           int C, int HW, int groups, float eps, int silu) {
+  __shared__ float sh[16];
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups, cpg = C / groups;
+  const size_t base = ((size_t)n * C + (size_t)g * cpg) * HW;
+  const int cnt = cpg * HW;
+  float s = 0.f, q = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += 256) { float v = x[base + i]; s += v; q += v * v; }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }  // wave64 shuffle reduction
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; sh[4 + (threadIdx.x >> 6)] = q; }
+  __syncthreads();
+  s = sh[0] + sh[1] + sh[2] + sh[3];
+  q = sh[4] + sh[5] + sh[6] + sh[7];
+  const float mean = s / cnt, var = fmaxf(q / cnt - mean * mean, 0.f), rstd = 1.0f / sqrtf(var + eps);
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int c = g * cpg + i / HW;
+    float v = (x[base + i] - mean) * rstd * gamma[c] + beta[c];
+    y[base + i] = silu ? silu_f<false>(v) : v;
+  }
+}
+
+}  // namespace
+
+int gn_affine_launch(const GnDesc& d, hipStream_t stream) {
+  const int C = d.C0 + d.C1;
+  const int V = d.dtype == 0 ? 4 : 8;
+  MI355_REQUIRE(C % d.groups == 0, -2, "groupnorm: channels not divisible by groups");
+  MI355_REQUIRE(d.C0 % V == 0 && d.C1 % V == 0, -2, "groupnorm: channels must be a multiple of the 16-byte fragment");
+  MI355_REQUIRE(C / V <= GN_THREADS, -4, "groupnorm: too many channels");
+  MI355_REQUIRE(d.groups <= GN_THREADS, -4, "groupnorm: too many groups");
+  GnKArgs a{d.src0, d.src1, d.C0, d.C1, d.N, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b};
+  const int ppi = GN_THREADS / (C / V);
+  const size_t lds = ((size_t)2 * ppi * C + 2 * C + 2 * d.groups) * sizeof(float);
+  if (d.dtype == 0) hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(d.N), dim3(GN_THREADS), lds, stream, a);
+  else hipLaunchKernelGGL(gn_affine_kernel<bf16>, dim3(d.N), dim3(GN_THREADS), lds, stream, a);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int groupnorm_nchw_launch(const float* x, const float* gamma, const float* beta, float* y, int N, int C, int HW, int groups,
+                          float eps, int silu, hipStream_t s) {
+  MI355_REQUIRE(C % groups == 0, -2, "groupnorm: channels not divisible by groups");
+  hipLaunchKernelGGL(groupnorm_nchw_kernel, dim3(N * groups), dim3(256), 0, s, x, gamma, beta, y, C, HW, groups, eps, silu);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}

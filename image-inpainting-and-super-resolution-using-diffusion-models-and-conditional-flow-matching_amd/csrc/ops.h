@@ -1,0 +1,106 @@
+// Internal C++ launch API shared by the U-Net executor, the sampler loops and the C ABI.
+#pragma once
+#include "common.h"
+
+// ---- implicit-GEMM convolution -------------------------------------------------------------------
+// Activations are NHWC in HBM ([N][H][W][C], element type float or bf16).  out[n, y, x, co] =
+//   bias[co] + emb[n, co] + res[...] + sum_{tap, ci} W[co, ci, tap] * P(in)[n, y*s + ky - pad, x*s + kx - pad, ci]
+// where P is the optional fused prologue  P(v) = silu?(a[n, ci] * v + b[n, ci])  (GroupNorm affine,
+// FiLM folded into a/b) evaluated while the input patch is staged into LDS, and `in` is read through
+// a gather: identity | nearest x2 upsample | 2x2 average pool (both applied AFTER P, as the reference
+// does: ResBlock up/down resamples between SiLU and the conv, unet.py:332-337).
+enum ConvMode { CONV_UNIT = 0, CONV_STRIDE2 = 1, CONV_UP2 = 2, CONV_POOL2 = 3 };
+enum ResMode { RES_NONE = 0, RES_SAME = 1, RES_UP2 = 2, RES_POOL2 = 3 };
+enum OutMode { OUT_NHWC = 0, OUT_NCHW_F32 = 1 };
+
+struct ConvDesc {
+  int dtype;                 // MI355_F32 / MI355_BF16
+  const void* src0 = nullptr; int C0 = 0;   // first source (channels = row stride of its NHWC tensor)
+  const void* src1 = nullptr; int C1 = 0;   // optional second source (skip concat, unet.py:725), never materialised
+  int N = 0, Hs = 0, Ws = 0;                // source spatial size
+  int mode = CONV_UNIT;
+  int ks = 3;
+  const float* pro_a = nullptr;             // [N][C0+C1] or null
+  const float* pro_b = nullptr;
+  int pro_silu = 0;
+  const void* w = nullptr;                  // packed by conv_pack_weights
+  const float* bias = nullptr;              // [Cout]
+  int Cout = 0;
+  const float* emb = nullptr; int emb_stride = 0;   // per-(n, co) additive term (ResBlock emb_layers)
+  const void* res = nullptr; int res_mode = RES_NONE;  // residual NHWC tensor with Cout channels
+  void* out = nullptr; int out_mode = OUT_NHWC;
+};
+
+struct ConvGeom {
+  int Ho, Wo, BM, BN;
+  size_t lds_bytes;
+  int grid_m, grid_n;
+};
+ConvGeom conv_geometry(const ConvDesc& d);
+// bytes of the packed weight image for a [Cout][Cin][ks][ks] filter
+size_t conv_packed_weight_bytes(int dtype, int Cout, int Cin, int ks);
+int conv_tile_n(int Cout);
+// host-side packing: w_host [Cout][Cin][ks][ks] fp32 (Cin = logical input channels; padded to a chunk)
+void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks, void* dst_host);
+int conv_launch(const ConvDesc& d, hipStream_t stream);
+
+// ---- GroupNorm statistics -> per-(n, channel) affine ----------------------------------------------
+// a[n,c] = rstd * gamma[c] (* (1 + film_scale)), b[n,c] = beta[c] - mean * rstd * gamma[c] (FiLM folded)
+struct GnDesc {
+  int dtype;
+  const void* src0 = nullptr; int C0 = 0;
+  const void* src1 = nullptr; int C1 = 0;
+  int N = 0, HW = 0;
+  int groups = 32;
+  float eps = 1e-5f;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* film = nullptr; int film_stride = 0;  // [N][2C]: scale | shift (use_scale_shift_norm)
+  float* a = nullptr;
+  float* b = nullptr;
+};
+int gn_affine_launch(const GnDesc& d, hipStream_t stream);
+
+// ---- attention --------------------------------------------------------------------------------------
+// qkv: NHWC [N][T][3*C] with the reference channel order (legacy: per head [q|k|v]; new: [q heads|k heads|v heads])
+// out: NHWC [N][T][C]
+struct AttnDesc {
+  int dtype;
+  const void* qkv = nullptr;
+  void* out = nullptr;
+  int N = 0, T = 0, heads = 0, ch = 0;
+  int new_order = 0;
+};
+int attention_launch(const AttnDesc& d, hipStream_t stream);
+
+// ---- small fp32 ops -----------------------------------------------------------------------------------
+int timestep_embedding_launch(const float* t, int B, int dim, float max_period, float* out, hipStream_t s);
+// out[b][j] = bias[j] + sum_k act(in[b][k]) * Wt[k][j]   (Wt = transposed weights, [K][J]); act: 0 none, 1 silu(in)
+// out_act: 0 none, 1 silu(out)
+int linear_launch(const float* in, const float* Wt, const float* bias, float* out, int B, int K, int J, int in_act,
+                  int out_act, hipStream_t s);
+
+// NCHW fp32 (x | cond) -> NHWC T with channels padded to Cpad (zero fill)
+int pack_nhwc_launch(int dtype, const float* x, int Cx, const float* cond, int Cc, int N, int HW, int Cpad, void* out,
+                     hipStream_t s);
+// NHWC T [N][HW][C] -> NCHW fp32
+int unpack_nchw_launch(int dtype, const void* in, int N, int HW, int C, float* out, hipStream_t s);
+// plain resampling of NHWC tensors (conv_resample=False paths): mode CONV_UP2 / CONV_POOL2
+int resample_launch(int dtype, const void* in, void* out, int N, int Hs, int Ws, int C, int mode, hipStream_t s);
+
+// elementwise sampler steps (steps.hip)
+int euler_step_launch(float* x, const float* v, float dt, int64_t n, hipStream_t s);
+int ddpm_step_launch(float* x, const float* eps, const float* z, float c_recip, float c_recipm1, float coef1, float coef2,
+                     float sigma, int use_philox, uint64_t seed, uint64_t offset, int64_t n, hipStream_t s);
+int corrector_step_launch(float* x, const float* eps, const float* z, float c_recip, float c_recipm1, float rsm1, float dt,
+                          float delta, int use_philox, uint64_t seed, uint64_t offset, int64_t n, hipStream_t s);
+int ddim_step_launch(float* x, const float* eps, float c_recip, float c_recipm1, float acp_prev, int64_t n, hipStream_t s);
+int replace_mask_launch(float* x, const float* cond, const float* z, float pad, int noisy, float sa, float sb,
+                        int use_philox, uint64_t seed, uint64_t offset, int64_t n, hipStream_t s);
+int clip_launch(float* x, float lo, float hi, int64_t n, hipStream_t s);
+int quantize_u8_launch(const float* x, uint8_t* out, int64_t n, hipStream_t s);
+int to_unit_range_launch(const float* x, float* out, int64_t n, hipStream_t s);
+int randn_launch(float* out, uint64_t seed, uint64_t offset, int64_t n, hipStream_t s);
+int fill_launch(float* x, float v, int64_t n, hipStream_t s);
+int groupnorm_nchw_launch(const float* x, const float* gamma, const float* beta, float* y, int N, int C, int HW, int groups,
+                          float eps, int silu, hipStream_t s);

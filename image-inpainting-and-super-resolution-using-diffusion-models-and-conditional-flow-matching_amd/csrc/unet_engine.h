@@ -1,0 +1,59 @@
+// U-Net layer plan + executor (host C++).  See unet_engine.hip.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/mi355_sampler.h"
+#include "ops.h"
+
+struct ParamInfo {
+  std::string name;
+  std::vector<int64_t> shape;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+// Parameter inventory in reference state_dict order (UNetModel.__init__, unet.py:564-706).
+int unet_enumerate_params(const mi355_unet_config& cfg, std::vector<ParamInfo>& out);
+
+struct PlanTensor { int C, H, W; bool f32; size_t offset_per_image; };  // element type T unless f32
+
+enum OpKind { OP_GN = 0, OP_CONV = 1, OP_ATTN = 2, OP_RESAMPLE = 3 };
+
+struct PlanOp {
+  int kind;
+  // common
+  int src0 = -1, src1 = -1, dst = -1;
+  // GN
+  size_t gamma_off = 0, beta_off = 0; int film_emb_off = -1;
+  // conv
+  int mode = 0, ks = 3, Cout = 0; size_t w_off = 0, bias_off = 0;
+  int use_pro = 0, pro_silu = 0; int emb_off = -1; int res = -1, res_mode = 0; int out_mode = 0;
+  // attention
+  int heads = 0, ch = 0;
+};
+
+struct mi355_unet {
+  mi355_unet_config cfg;
+  std::vector<ParamInfo> params;
+  std::vector<PlanTensor> tensors;
+  std::vector<PlanOp> ops;
+  char* dev_weights = nullptr;
+  int64_t dev_weights_bytes = 0;
+  // fp32 side tables in the weight blob
+  size_t te_w0 = 0, te_b0 = 0, te_w2 = 0, te_b2 = 0, emb_w = 0, emb_b = 0;
+  int emb_total = 0;   // concatenated emb_layers output channels of all ResBlocks
+  int in_pad = 0;      // first conv's padded input channels
+  int max_gn_c = 0;
+  size_t act_elems_per_image = 0;  // activation arena (elements of T) per image
+  int in_tensor = -1, out_channels = 0;
+  // stats per image
+  double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;
+  int64_t launches = 0;
+};
+
+int unet_build(const mi355_unet_config& cfg, const float* const* params_host, int n_params, void* dev_weights,
+               int64_t dev_weights_bytes, hipStream_t stream, mi355_unet** out);
+int64_t unet_weight_bytes(const mi355_unet_config& cfg);
+int64_t unet_workspace_bytes(const mi355_unet* net, int batch);
+int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int batch,
+                 void* workspace, int64_t workspace_bytes, hipStream_t stream);

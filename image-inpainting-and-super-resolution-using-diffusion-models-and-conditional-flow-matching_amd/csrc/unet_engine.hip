@@ -1,0 +1,441 @@
+// U-Net layer plan, weight packer and executor.
+//
+// Rebuilds the wiring of UNetModel.__init__/forward (AD/image_diffusion/unet.py:521-728; identical to
+// torchcfm's UNetModelWrapper used by cifar10/ and mnist/) as a flat list of fused device ops:
+//   ResBlock  (unet.py:331-351) = GN-stats, conv3x3[GN+SiLU prologue, +emb epilogue], GN-stats(+FiLM),
+//                                  (1x1 skip conv), conv3x3[GN+SiLU prologue, +skip epilogue]
+//   Attention (unet.py:395-401) = GN-stats, 1x1 conv[GN prologue] -> qkv, fused attention, 1x1 conv[+x]
+//   Down/Upsample, skip concat, nearest-up / avg-pool are gather modes of the consuming conv.
+// Parameters arrive in the reference's state_dict order and layouts and are repacked once.
+#include "unet_engine.h"
+
+#include <cstring>
+#include <map>
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Walker {
+  mi355_unet_config cfg;
+  int dtype, esz, CH;
+  bool dry;
+  const float* const* host = nullptr;
+  std::vector<ParamInfo> params;
+  std::map<std::string, int> pidx;
+  std::vector<char> blob;
+  size_t cursor = 0;
+  mi355_unet* net = nullptr;
+  std::string err;
+  struct EmbPart { std::string name; int off, width; };
+  std::vector<EmbPart> emb_parts;
+  int emb_total = 0;
+
+  bool has_attn(int ds) const {
+    for (int i = 0; i < cfg.n_attention_ds; ++i) if (cfg.attention_ds[i] == ds) return true;
+    return false;
+  }
+  int heads_for(int ch, bool upsample) const {  // unet.py:370-378
+    if (cfg.num_head_channels == -1) {
+      int nh = (upsample && cfg.num_heads_upsample != -1) ? cfg.num_heads_upsample : cfg.num_heads;
+      return nh;
+    }
+    return ch / cfg.num_head_channels;
+  }
+
+  size_t alloc(size_t bytes) {
+    size_t o = cursor;
+    cursor = align_up(cursor + bytes, 256);
+    if (!dry) blob.resize(cursor, 0);
+    return o;
+  }
+  const float* P(const std::string& name, std::vector<int64_t> expect) {
+    auto it = pidx.find(name);
+    if (it == pidx.end()) { err = "missing parameter " + name; return nullptr; }
+    if (params[it->second].shape != expect) { err = "shape mismatch for " + name; return nullptr; }
+    return dry ? nullptr : host[it->second];
+  }
+  size_t put_f32(const std::string& name, std::vector<int64_t> shape) {
+    const float* p = P(name, shape);
+    int64_t n = 1; for (auto s : shape) n *= s;
+    size_t o = alloc((size_t)n * 4);
+    if (!dry && p) memcpy(blob.data() + o, p, (size_t)n * 4);
+    return o;
+  }
+  size_t put_conv(const std::string& name, int Cout, int Cin, int ks, bool conv1d) {
+    std::vector<int64_t> shape = conv1d ? std::vector<int64_t>{Cout, Cin, 1} : std::vector<int64_t>{Cout, Cin, ks, ks};
+    const float* p = P(name, shape);
+    size_t bytes = conv_packed_weight_bytes(dtype, Cout, Cin, ks);
+    size_t o = alloc(bytes);
+    if (!dry && p) conv_pack_weights(dtype, p, Cout, Cin, ks, blob.data() + o);
+    net->weight_bytes += (double)Cout * Cin * ks * ks * esz;
+    return o;
+  }
+  size_t put_linear_t(const std::string& name, int J, int K) {  // W [J][K] -> Wt [K][J]
+    const float* p = P(name, {J, K});
+    size_t o = alloc((size_t)J * K * 4);
+    if (!dry && p) {
+      float* d = reinterpret_cast<float*>(blob.data() + o);
+      for (int j = 0; j < J; ++j) for (int k = 0; k < K; ++k) d[(size_t)k * J + j] = p[(size_t)j * K + k];
+    }
+    return o;
+  }
+
+  int tensor(int C, int H, int W) {
+    PlanTensor t{C, H, W, false, net->act_elems_per_image};
+    net->act_elems_per_image += align_up((size_t)C * H * W, 128);
+    net->tensors.push_back(t);
+    return (int)net->tensors.size() - 1;
+  }
+  const PlanTensor& T(int id) const { return net->tensors[id]; }
+
+  void add_gn(int s0, int s1, const std::string& wname, const std::string& bname, int film_off) {
+    const int C = T(s0).C + (s1 >= 0 ? T(s1).C : 0);
+    PlanOp op; op.kind = OP_GN; op.src0 = s0; op.src1 = s1;
+    op.gamma_off = put_f32(wname, {C}); op.beta_off = put_f32(bname, {C}); op.film_emb_off = film_off;
+    net->ops.push_back(op);
+    if (C > net->max_gn_c) net->max_gn_c = C;
+  }
+  // returns dst tensor (or -1 for the NCHW fp32 network output)
+  int add_conv(const std::string& prefix, int s0, int s1, int Cin_logical, int Cout, int ks, int mode, bool conv1d, int use_pro,
+               int pro_silu, int emb_off, int res, int res_mode, int out_mode) {
+    PlanOp op; op.kind = OP_CONV; op.src0 = s0; op.src1 = s1; op.mode = mode; op.ks = ks; op.Cout = Cout;
+    op.w_off = put_conv(prefix + ".weight", Cout, Cin_logical, ks, conv1d);
+    op.bias_off = put_f32(prefix + ".bias", {Cout});
+    op.use_pro = use_pro; op.pro_silu = pro_silu; op.emb_off = emb_off; op.res = res; op.res_mode = res_mode; op.out_mode = out_mode;
+    int Ho = T(s0).H, Wo = T(s0).W;
+    if (mode == CONV_UP2) { Ho *= 2; Wo *= 2; }
+    else if (mode == CONV_POOL2) { Ho /= 2; Wo /= 2; }
+    else if (mode == CONV_STRIDE2) { Ho = (Ho - 1) / 2 + 1; Wo = (Wo - 1) / 2 + 1; }
+    op.dst = out_mode == OUT_NHWC ? tensor(Cout, Ho, Wo) : -1;
+    net->ops.push_back(op);
+    const double in_elems = (double)(T(s0).C + (s1 >= 0 ? T(s1).C : 0)) * T(s0).H * T(s0).W;
+    net->conv_flops += 2.0 * Ho * Wo * (double)Cout * Cin_logical * ks * ks;
+    net->act_bytes += (in_elems + (double)Cout * Ho * Wo) * esz;
+    return op.dst;
+  }
+
+  int res_block(const std::string& p, int s0, int s1, int cin, int cout, bool up, bool down) {
+    const bool film = cfg.use_scale_shift_norm != 0;
+    const int ew = film ? 2 * cout : cout;
+    const int eoff = emb_total;
+    emb_parts.push_back({p + ".emb_layers.1", eoff, ew});
+    emb_total += ew;
+    P(p + ".emb_layers.1.weight", {ew, 4 * cfg.model_channels});
+    P(p + ".emb_layers.1.bias", {ew});
+    add_gn(s0, s1, p + ".in_layers.0.weight", p + ".in_layers.0.bias", -1);
+    const int mode = up ? CONV_UP2 : (down ? CONV_POOL2 : CONV_UNIT);
+    const int h1 = add_conv(p + ".in_layers.2", s0, s1, cin, cout, 3, mode, false, 1, 1, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC);
+    add_gn(h1, -1, p + ".out_layers.0.weight", p + ".out_layers.0.bias", film ? eoff : -1);
+    int res = s0, res_mode = up ? RES_UP2 : (down ? RES_POOL2 : RES_SAME);
+    if (cin != cout) {
+      if (up || down) { err = "ResBlock(up/down) with a channel change is not supported"; return -1; }
+      auto it = pidx.find(p + ".skip_connection.weight");
+      const int sks = (it != pidx.end() && params[it->second].shape.size() == 4) ? (int)params[it->second].shape[3] : 1;
+      res = add_conv(p + ".skip_connection", s0, s1, cin, cout, sks, CONV_UNIT, false, 0, 0, -1, -1, RES_NONE, OUT_NHWC);
+      res_mode = RES_SAME;
+    } else if (s1 >= 0) {
+      err = "identity skip over a channel concat is not supported";
+      return -1;
+    }
+    return add_conv(p + ".out_layers.3", h1, -1, cout, cout, 3, CONV_UNIT, false, 1, 1, -1, res, res_mode, OUT_NHWC);
+  }
+
+  int attn_block(const std::string& p, int x, int C, int heads) {
+    if (heads <= 0 || C % heads != 0) { err = "attention: bad head count"; return -1; }
+    const int ch = C / heads;
+    if (ch != 32 && ch != 64 && ch != 128) { err = "attention: head channels must be 32, 64 or 128 (got " + std::to_string(ch) + ")"; return -1; }
+    add_gn(x, -1, p + ".norm.weight", p + ".norm.bias", -1);
+    const int qkv = add_conv(p + ".qkv", x, -1, C, 3 * C, 1, CONV_UNIT, true, 1, 0, -1, -1, RES_NONE, OUT_NHWC);
+    PlanOp op; op.kind = OP_ATTN; op.src0 = qkv; op.heads = heads; op.ch = ch;
+    op.dst = tensor(C, T(x).H, T(x).W);
+    net->ops.push_back(op);
+    const double Tn = (double)T(x).H * T(x).W;
+    net->attn_flops += 4.0 * Tn * Tn * C;
+    net->act_bytes += (4.0 * C * Tn) * esz;
+    return add_conv(p + ".proj_out", op.dst, -1, C, C, 1, CONV_UNIT, true, 0, 0, -1, x, RES_SAME, OUT_NHWC);
+  }
+
+  int resample(int x, int mode) {
+    PlanOp op; op.kind = OP_RESAMPLE; op.src0 = x; op.mode = mode;
+    const int Ho = mode == CONV_UP2 ? T(x).H * 2 : T(x).H / 2, Wo = mode == CONV_UP2 ? T(x).W * 2 : T(x).W / 2;
+    op.dst = tensor(T(x).C, Ho, Wo);
+    net->ops.push_back(op);
+    return op.dst;
+  }
+
+  int walk() {
+    const int mc = cfg.model_channels, nl = cfg.n_channel_mult;
+    const int S = cfg.image_size;
+    net->in_pad = (int)align_up(cfg.in_channels, CH);
+    net->te_w0 = put_linear_t("time_embed.0.weight", 4 * mc, mc);
+    net->te_b0 = put_f32("time_embed.0.bias", {4 * mc});
+    net->te_w2 = put_linear_t("time_embed.2.weight", 4 * mc, 4 * mc);
+    net->te_b2 = put_f32("time_embed.2.bias", {4 * mc});
+    int ch = cfg.channel_mult[0] * mc;
+    const int input_ch = ch;
+    net->in_tensor = tensor(net->in_pad, S, S);
+    int h = add_conv("input_blocks.0.0", net->in_tensor, -1, cfg.in_channels, ch, 3, CONV_UNIT, false, 0, 0, -1, -1, RES_NONE, OUT_NHWC);
+    std::vector<int> hs{h};
+    int ds = 1, idx = 1;
+    for (int level = 0; level < nl && err.empty(); ++level) {
+      const int mult = cfg.channel_mult[level];
+      for (int r = 0; r < cfg.num_res_blocks && err.empty(); ++r, ++idx) {
+        const std::string p = "input_blocks." + std::to_string(idx);
+        h = res_block(p + ".0", h, -1, ch, mult * mc, false, false);
+        ch = mult * mc;
+        if (has_attn(ds) && err.empty()) h = attn_block(p + ".1", h, ch, heads_for(ch, false));
+        hs.push_back(h);
+      }
+      if (level != nl - 1 && err.empty()) {
+        const std::string p = "input_blocks." + std::to_string(idx) + ".0";
+        if (cfg.resblock_updown) h = res_block(p, h, -1, ch, ch, false, true);
+        else if (cfg.conv_resample) h = add_conv(p + ".op", h, -1, ch, ch, 3, CONV_STRIDE2, false, 0, 0, -1, -1, RES_NONE, OUT_NHWC);
+        else h = resample(h, CONV_POOL2);
+        hs.push_back(h);
+        ds *= 2; ++idx;
+      }
+    }
+    if (!err.empty()) return -1;
+    h = res_block("middle_block.0", h, -1, ch, ch, false, false);
+    if (err.empty()) h = attn_block("middle_block.1", h, ch, heads_for(ch, false));
+    if (err.empty()) h = res_block("middle_block.2", h, -1, ch, ch, false, false);
+    idx = 0;
+    for (int level = nl - 1; level >= 0 && err.empty(); --level) {
+      const int mult = cfg.channel_mult[level];
+      for (int i = 0; i <= cfg.num_res_blocks && err.empty(); ++i, ++idx) {
+        const std::string p = "output_blocks." + std::to_string(idx);
+        const int skip = hs.back(); hs.pop_back();
+        const int ich = T(skip).C;
+        h = res_block(p + ".0", h, skip, ch + ich, mc * mult, false, false);
+        ch = mc * mult;
+        int j = 1;
+        if (has_attn(ds) && err.empty()) { h = attn_block(p + "." + std::to_string(j), h, ch, heads_for(ch, true)); ++j; }
+        if (level && i == cfg.num_res_blocks && err.empty()) {
+          const std::string q = p + "." + std::to_string(j);
+          if (cfg.resblock_updown) h = res_block(q, h, -1, ch, ch, true, false);
+          else if (cfg.conv_resample) h = add_conv(q + ".conv", h, -1, ch, ch, 3, CONV_UP2, false, 0, 0, -1, -1, RES_NONE, OUT_NHWC);
+          else h = resample(h, CONV_UP2);
+          ds /= 2;
+        }
+      }
+    }
+    if (!err.empty()) return -1;
+    add_gn(h, -1, "out.0.weight", "out.0.bias", -1);
+    add_conv("out.2", h, -1, input_ch, cfg.out_channels, 3, CONV_UNIT, false, 1, 1, -1, -1, RES_NONE, OUT_NCHW_F32);
+    if (!err.empty()) return -1;
+    // batched emb_layers: Wt [4mc][emb_total], bias [emb_total]
+    const int K = 4 * mc;
+    net->emb_total = emb_total;
+    net->emb_w = alloc((size_t)K * emb_total * 4);
+    net->emb_b = alloc((size_t)emb_total * 4);
+    if (!dry) {
+      float* W = reinterpret_cast<float*>(blob.data() + net->emb_w);
+      float* Bv = reinterpret_cast<float*>(blob.data() + net->emb_b);
+      for (auto& e : emb_parts) {
+        const float* w = host[pidx[e.name + ".weight"]];
+        const float* b = host[pidx[e.name + ".bias"]];
+        for (int j = 0; j < e.width; ++j) {
+          Bv[e.off + j] = b[j];
+          for (int k = 0; k < K; ++k) W[(size_t)k * emb_total + e.off + j] = w[(size_t)j * K + k];
+        }
+      }
+    }
+    net->conv_flops += 2.0 * (double)K * emb_total + 2.0 * (double)mc * K + 2.0 * (double)K * K;
+    net->out_channels = cfg.out_channels;
+    return 0;
+  }
+};
+
+int check_cfg(const mi355_unet_config& c) {
+  MI355_REQUIRE(c.dtype == MI355_F32 || c.dtype == MI355_BF16, -1, "unet: dtype must be MI355_F32 or MI355_BF16");
+  MI355_REQUIRE(c.n_channel_mult >= 1 && c.n_channel_mult <= 8 && c.n_attention_ds >= 0 && c.n_attention_ds <= 8, -1, "unet: bad config arrays");
+  MI355_REQUIRE(c.model_channels % 32 == 0 && c.model_channels > 0, -4, "unet: model_channels must be a multiple of 32 (GroupNorm32 + 64-byte channel chunks)");
+  MI355_REQUIRE(c.in_channels > 0 && c.in_channels <= 32 && c.out_channels > 0 && c.out_channels <= 32, -4, "unet: in/out channels must be in 1..32");
+  MI355_REQUIRE(c.image_size > 0 && c.num_res_blocks > 0, -1, "unet: bad sizes");
+  return 0;
+}
+
+}  // namespace
+
+int unet_enumerate_params(const mi355_unet_config& cfg, std::vector<ParamInfo>& out) {
+  if (int rc = check_cfg(cfg)) return rc;
+  out.clear();
+  const int mc = cfg.model_channels, E = 4 * mc, nl = cfg.n_channel_mult;
+  auto add = [&](const std::string& n, std::vector<int64_t> s) { out.push_back({n, s}); };
+  auto conv = [&](const std::string& p, int co, int ci, int k) { add(p + ".weight", {co, ci, k, k}); add(p + ".bias", {co}); };
+  auto res = [&](const std::string& p, int cin, int cout) {
+    add(p + ".in_layers.0.weight", {cin}); add(p + ".in_layers.0.bias", {cin});
+    conv(p + ".in_layers.2", cout, cin, 3);
+    const int ew = cfg.use_scale_shift_norm ? 2 * cout : cout;
+    add(p + ".emb_layers.1.weight", {ew, E}); add(p + ".emb_layers.1.bias", {ew});
+    add(p + ".out_layers.0.weight", {cout}); add(p + ".out_layers.0.bias", {cout});
+    conv(p + ".out_layers.3", cout, cout, 3);
+    if (cin != cout) conv(p + ".skip_connection", cout, cin, 1);
+  };
+  auto attn = [&](const std::string& p, int C) {
+    add(p + ".norm.weight", {C}); add(p + ".norm.bias", {C});
+    add(p + ".qkv.weight", {3 * C, C, 1}); add(p + ".qkv.bias", {3 * C});
+    add(p + ".proj_out.weight", {C, C, 1}); add(p + ".proj_out.bias", {C});
+  };
+  auto has_attn = [&](int ds) { for (int i = 0; i < cfg.n_attention_ds; ++i) if (cfg.attention_ds[i] == ds) return true; return false; };
+  add("time_embed.0.weight", {E, mc}); add("time_embed.0.bias", {E});
+  add("time_embed.2.weight", {E, E}); add("time_embed.2.bias", {E});
+  int ch = cfg.channel_mult[0] * mc;
+  const int input_ch = ch;
+  conv("input_blocks.0.0", ch, cfg.in_channels, 3);
+  std::vector<int> chans{ch};
+  int ds = 1, idx = 1;
+  for (int level = 0; level < nl; ++level) {
+    const int mult = cfg.channel_mult[level];
+    for (int r = 0; r < cfg.num_res_blocks; ++r, ++idx) {
+      const std::string p = "input_blocks." + std::to_string(idx);
+      res(p + ".0", ch, mult * mc);
+      ch = mult * mc;
+      if (has_attn(ds)) attn(p + ".1", ch);
+      chans.push_back(ch);
+    }
+    if (level != nl - 1) {
+      const std::string p = "input_blocks." + std::to_string(idx) + ".0";
+      if (cfg.resblock_updown) res(p, ch, ch);
+      else if (cfg.conv_resample) conv(p + ".op", ch, ch, 3);
+      chans.push_back(ch);
+      ds *= 2; ++idx;
+    }
+  }
+  res("middle_block.0", ch, ch); attn("middle_block.1", ch); res("middle_block.2", ch, ch);
+  idx = 0;
+  for (int level = nl - 1; level >= 0; --level) {
+    const int mult = cfg.channel_mult[level];
+    for (int i = 0; i <= cfg.num_res_blocks; ++i, ++idx) {
+      const std::string p = "output_blocks." + std::to_string(idx);
+      const int ich = chans.back(); chans.pop_back();
+      res(p + ".0", ch + ich, mc * mult);
+      ch = mc * mult;
+      int j = 1;
+      if (has_attn(ds)) { attn(p + "." + std::to_string(j), ch); ++j; }
+      if (level && i == cfg.num_res_blocks) {
+        const std::string q = p + "." + std::to_string(j);
+        if (cfg.resblock_updown) res(q, ch, ch);
+        else if (cfg.conv_resample) conv(q + ".conv", ch, ch, 3);
+        ds /= 2;
+      }
+    }
+  }
+  add("out.0.weight", {ch}); add("out.0.bias", {ch});
+  conv("out.2", cfg.out_channels, input_ch, 3);
+  return 0;
+}
+
+static int run_walker(const mi355_unet_config& cfg, const float* const* host, mi355_unet* net, Walker& w) {
+  w.cfg = cfg; w.dtype = cfg.dtype; w.esz = cfg.dtype == 0 ? 4 : 2; w.CH = cfg.dtype == 0 ? 16 : 32;
+  w.dry = host == nullptr; w.host = host; w.net = net;
+  if (int rc = unet_enumerate_params(cfg, w.params)) return rc;
+  for (size_t i = 0; i < w.params.size(); ++i) w.pidx[w.params[i].name] = (int)i;
+  net->cfg = cfg;
+  if (w.walk() != 0 || !w.err.empty()) { mi355_set_error("unet plan: " + w.err); return -4; }
+  return 0;
+}
+
+int64_t unet_weight_bytes(const mi355_unet_config& cfg) {
+  mi355_unet tmp; Walker w;
+  if (int rc = run_walker(cfg, nullptr, &tmp, w)) return rc;
+  return (int64_t)w.cursor;
+}
+
+int unet_build(const mi355_unet_config& cfg, const float* const* params_host, int n_params, void* dev_weights,
+               int64_t dev_weights_bytes, hipStream_t stream, mi355_unet** out) {
+  MI355_REQUIRE(params_host && dev_weights && out, -1, "unet_create: null argument");
+  mi355_unet* net = new mi355_unet();
+  Walker w;
+  int rc = run_walker(cfg, params_host, net, w);
+  if (rc == 0 && n_params != (int)w.params.size()) { mi355_set_error("unet_create: parameter count mismatch"); rc = -2; }
+  if (rc == 0 && (int64_t)w.cursor > dev_weights_bytes) { mi355_set_error("unet_create: device weight buffer too small"); rc = -2; }
+  if (rc == 0) {
+    hipError_t e = hipMemcpyAsync(dev_weights, w.blob.data(), w.cursor, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // blob is a temporary: creation is a one-off, not a hot path
+    if (e != hipSuccess) { mi355_set_error(std::string("unet_create: weight upload: ") + hipGetErrorString(e)); rc = -3; }
+  }
+  if (rc) { delete net; return rc; }
+  net->params = w.params;
+  net->dev_weights = reinterpret_cast<char*>(dev_weights);
+  net->dev_weights_bytes = (int64_t)w.cursor;
+  *out = net;
+  return 0;
+}
+
+namespace {
+struct WsLayout { size_t temb, emb1, emb2, embp, gna, gnb, arena, total; };
+WsLayout ws_layout(const mi355_unet* net, int B) {
+  const int mc = net->cfg.model_channels, esz = net->cfg.dtype == 0 ? 4 : 2;
+  WsLayout l; size_t c = 0;
+  auto take = [&](size_t bytes) { size_t o = c; c = align_up(c + bytes, 256); return o; };
+  l.temb = take((size_t)B * mc * 4);
+  l.emb1 = take((size_t)B * 4 * mc * 4);
+  l.emb2 = take((size_t)B * 4 * mc * 4);
+  l.embp = take((size_t)B * net->emb_total * 4);
+  l.gna = take((size_t)B * net->max_gn_c * 4);
+  l.gnb = take((size_t)B * net->max_gn_c * 4);
+  l.arena = take(net->act_elems_per_image * (size_t)B * esz);
+  l.total = c;
+  return l;
+}
+}  // namespace
+
+int64_t unet_workspace_bytes(const mi355_unet* net, int batch) { return (int64_t)ws_layout(net, batch).total; }
+
+int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int B,
+                 void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  MI355_REQUIRE(net && x && t && out && workspace, -1, "unet_forward: null argument");
+  MI355_REQUIRE(B > 0, -1, "unet_forward: batch must be positive");
+  MI355_REQUIRE(Cx + (cond ? Cc : 0) == net->cfg.in_channels, -2, "unet_forward: x/cond channels do not add up to in_channels");
+  const WsLayout l = ws_layout(net, B);
+  MI355_REQUIRE((int64_t)l.total <= workspace_bytes, -2, "unet_forward: workspace too small");
+  MI355_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, -1, "unet_forward: workspace must be 256-byte aligned");
+  const int dtype = net->cfg.dtype, esz = dtype == 0 ? 4 : 2, mc = net->cfg.model_channels;
+  char* ws = reinterpret_cast<char*>(workspace);
+  char* W = net->dev_weights;
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+  auto WF = [&](size_t off) { return reinterpret_cast<const float*>(W + off); };
+  auto TP = [&](int id) -> void* { return id < 0 ? nullptr : ws + l.arena + net->tensors[id].offset_per_image * (size_t)B * esz; };
+  int rc;
+  net->launches = 0;
+  // time embedding path (fp32): emb2 = silu(time_embed(timestep_embedding(t))) ; embp = all emb_layers linears
+  if ((rc = timestep_embedding_launch(t, B, mc, 10000.f, F(l.temb), stream))) return rc;
+  if ((rc = linear_launch(F(l.temb), WF(net->te_w0), WF(net->te_b0), F(l.emb1), B, mc, 4 * mc, 0, 1, stream))) return rc;
+  if ((rc = linear_launch(F(l.emb1), WF(net->te_w2), WF(net->te_b2), F(l.emb2), B, 4 * mc, 4 * mc, 0, 1, stream))) return rc;
+  if ((rc = linear_launch(F(l.emb2), WF(net->emb_w), WF(net->emb_b), F(l.embp), B, 4 * mc, net->emb_total, 0, 0, stream))) return rc;
+  const int S = net->cfg.image_size;
+  if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
+  net->launches += 5;
+  for (const PlanOp& op : net->ops) {
+    const PlanTensor& s0 = net->tensors[op.src0];
+    const int C1 = op.src1 >= 0 ? net->tensors[op.src1].C : 0;
+    if (op.kind == OP_GN) {
+      GnDesc g; g.dtype = dtype; g.src0 = TP(op.src0); g.C0 = s0.C; g.src1 = TP(op.src1); g.C1 = C1;
+      g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
+      if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = net->emb_total; }
+      g.a = F(l.gna); g.b = F(l.gnb);
+      rc = gn_affine_launch(g, stream);
+    } else if (op.kind == OP_CONV) {
+      ConvDesc c; c.dtype = dtype; c.src0 = TP(op.src0); c.C0 = s0.C; c.src1 = TP(op.src1); c.C1 = C1;
+      c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks;
+      if (op.use_pro) { c.pro_a = F(l.gna); c.pro_b = F(l.gnb); c.pro_silu = op.pro_silu; }
+      c.w = W + op.w_off; c.bias = WF(op.bias_off); c.Cout = op.Cout;
+      if (op.emb_off >= 0) { c.emb = F(l.embp) + op.emb_off; c.emb_stride = net->emb_total; }
+      if (op.res >= 0) { c.res = TP(op.res); c.res_mode = op.res_mode; }
+      c.out_mode = op.out_mode;
+      c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
+      rc = conv_launch(c, stream);
+    } else if (op.kind == OP_ATTN) {
+      AttnDesc a; a.dtype = dtype; a.qkv = TP(op.src0); a.out = TP(op.dst); a.N = B; a.T = s0.H * s0.W;
+      a.heads = op.heads; a.ch = op.ch; a.new_order = net->cfg.use_new_attention_order;
+      rc = attention_launch(a, stream);
+    } else {
+      rc = resample_launch(dtype, TP(op.src0), TP(op.dst), B, s0.H, s0.W, s0.C, op.mode, stream);
+    }
+    if (rc) return rc;
+    ++net->launches;
+  }
+  return 0;
+}

@@ -1,0 +1,155 @@
+"""ctypes binding of csrc/libmi355_sampler.so (C ABI: include/mi355_sampler.h).
+
+There is NO fallback: if the shared library is missing or cannot be loaded, every product entry
+point raises `MI355BackendError`.  Nothing in this package computes on the CPU or through PyTorch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+LIB_PATH = os.path.join(CSRC, "libmi355_sampler.so")
+
+MI355_F32, MI355_BF16 = 0, 1
+DDPM_PRIOR, DDPM_AMORTIZED, DDPM_REPLACEMENT, DDIM = 0, 1, 2, 3
+
+
+class MI355BackendError(RuntimeError):
+    pass
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [
+        ("image_size", C.c_int32), ("in_channels", C.c_int32), ("model_channels", C.c_int32),
+        ("out_channels", C.c_int32), ("num_res_blocks", C.c_int32), ("n_attention_ds", C.c_int32),
+        ("attention_ds", C.c_int32 * 8), ("n_channel_mult", C.c_int32), ("channel_mult", C.c_int32 * 8),
+        ("conv_resample", C.c_int32), ("num_heads", C.c_int32), ("num_head_channels", C.c_int32),
+        ("num_heads_upsample", C.c_int32), ("use_scale_shift_norm", C.c_int32), ("resblock_updown", C.c_int32),
+        ("use_new_attention_order", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
+class UNetStatsC(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("conv_flops", C.c_double), ("attn_flops", C.c_double),
+                ("act_bytes", C.c_double), ("weight_bytes", C.c_double)]
+
+
+_FP = C.POINTER(C.c_float)
+
+
+class DDPMTablesC(C.Structure):
+    _fields_ = [("Ns", C.c_int32)] + [(n, _FP) for n in (
+        "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+        "posterior_log_variance_clipped", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+        "recip_sqrt_m1_alphas_cumprod", "alphas_cumprod_prev")]
+
+
+class DDPMOptionsC(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n_corrector", C.c_int32), ("delta", C.c_float), ("tmin", C.c_float),
+                ("tmax", C.c_float), ("start_fraction", C.c_float), ("noise_condition", C.c_int32),
+                ("pad_value", C.c_float), ("none_value", C.c_float), ("cond_is_none", C.c_int32), ("seed", C.c_uint64)]
+
+
+_VP, _I, _I64, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "mi355_version": (_I, []),
+    "mi355_last_error": (C.c_char_p, []),
+    "mi355_unet_param_count": (_I, [C.POINTER(UNetConfigC)]),
+    "mi355_unet_param_info": (_I, [C.POINTER(UNetConfigC), _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "mi355_unet_weight_bytes": (_I64, [C.POINTER(UNetConfigC)]),
+    "mi355_unet_create": (_I, [C.POINTER(UNetConfigC), C.POINTER(_VP), _I, _VP, _I64, _VP, C.POINTER(_VP)]),
+    "mi355_unet_destroy": (None, [_VP]),
+    "mi355_unet_workspace_bytes": (_I64, [_VP, _I]),
+    "mi355_unet_forward": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
+    "mi355_unet_get_stats": (_I, [_VP, _I, C.POINTER(UNetStatsC)]),
+    "mi355_cfm_euler_sample": (_I, [_VP, _VP, _I, _VP, _I, _FP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
+    "mi355_ddpm_sample": (_I, [_VP, _VP, _I, _VP, C.POINTER(DDPMTablesC), C.POINTER(DDPMOptionsC), _VP, _I64, _I, _VP, _I64, _VP]),
+    "mi355_timestep_embedding": (_I, [_VP, _I, _I, _F, _VP, _VP]),
+    "mi355_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP]),
+    "mi355_euler_step": (_I, [_VP, _VP, _F, _I64, _VP]),
+    "mi355_ddpm_step": (_I, [_VP, _VP, _VP, _F, _F, _F, _F, _F, _I, _U64, _U64, _I64, _VP]),
+    "mi355_corrector_step": (_I, [_VP, _VP, _VP, _F, _F, _F, _F, _F, _I, _U64, _U64, _I64, _VP]),
+    "mi355_ddim_step": (_I, [_VP, _VP, _F, _F, _F, _I64, _VP]),
+    "mi355_replace_mask": (_I, [_VP, _VP, _VP, _F, _I, _F, _F, _I, _U64, _U64, _I64, _VP]),
+    "mi355_clip": (_I, [_VP, _F, _F, _I64, _VP]),
+    "mi355_quantize_u8": (_I, [_VP, _VP, _I64, _VP]),
+    "mi355_to_unit_range": (_I, [_VP, _VP, _I64, _VP]),
+    "mi355_randn": (_I, [_VP, _U64, _U64, _I64, _VP]),
+    "mi355_op_workspace_bytes": (_I64, [_I, _I, _I]),
+    "mi355_conv2d": (_I, [_VP, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _I64, _VP]),
+    "mi355_qkv_attention": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I64, _VP]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise MI355BackendError("building libmi355_sampler.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library (once) and type every entry point.  Raises if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MI355BackendError(
+                f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "This package has no CPU or PyTorch fallback.")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise MI355BackendError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+        return L
+
+
+def check(rc: int, what: str = ""):
+    if rc is not None and rc < 0:
+        msg = lib().mi355_last_error().decode("utf-8", "replace")
+        raise MI355BackendError(f"{what or 'libmi355_sampler'} failed ({rc}): {msg}")
+    return rc
+
+
+def make_config(*, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_ds, channel_mult,
+                conv_resample=True, num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                resblock_updown=False, use_new_attention_order=False, dtype=MI355_BF16) -> UNetConfigC:
+    c = UNetConfigC()
+    c.image_size, c.in_channels, c.model_channels, c.out_channels = image_size, in_channels, model_channels, out_channels
+    c.num_res_blocks = num_res_blocks
+    attention_ds = list(attention_ds)
+    channel_mult = list(channel_mult)
+    if len(attention_ds) > 8 or len(channel_mult) > 8:
+        raise ValueError("at most 8 attention resolutions / channel multipliers")
+    for m in channel_mult:
+        if int(m) != m:
+            raise ValueError("only integer channel multipliers are supported by the HIP plan")
+    c.n_attention_ds = len(attention_ds)
+    for i, v in enumerate(attention_ds):
+        c.attention_ds[i] = int(v)
+    c.n_channel_mult = len(channel_mult)
+    for i, v in enumerate(channel_mult):
+        c.channel_mult[i] = int(v)
+    c.conv_resample, c.num_heads, c.num_head_channels = int(conv_resample), num_heads, num_head_channels
+    c.num_heads_upsample = num_heads_upsample
+    c.use_scale_shift_norm, c.resblock_updown = int(use_scale_shift_norm), int(resblock_updown)
+    c.use_new_attention_order, c.dtype = int(use_new_attention_order), dtype
+    return c

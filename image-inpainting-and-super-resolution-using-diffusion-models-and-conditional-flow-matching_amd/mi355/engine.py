@@ -1,0 +1,165 @@
+"""UNetEngine: one packed-weight U-Net handle of libmi355_sampler.so plus its workspace.
+
+PyTorch is used for device memory (weight blob, workspace, I/O tensors) and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import MI355BackendError, check
+
+_PREC = {"fp32": _lib.MI355_F32, "f32": _lib.MI355_F32, "bf16": _lib.MI355_BF16}
+
+
+def param_inventory(cfg: _lib.UNetConfigC):
+    """(name, shape) list from the C++ plan builder, reference state_dict order."""
+    L = _lib.lib()
+    n = check(L.mi355_unet_param_count(C.byref(cfg)), "mi355_unet_param_count")
+    out = []
+    name = C.create_string_buffer(256)
+    shape = (C.c_int64 * 4)()
+    nd = C.c_int()
+    for i in range(n):
+        check(L.mi355_unet_param_info(C.byref(cfg), i, name, 256, shape, C.byref(nd)))
+        out.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value))))
+    return out
+
+
+class UNetEngine:
+    def __init__(self, cfg_kwargs: dict, state_dict: Dict[str, torch.Tensor], device, precision: str = "bf16"):
+        if precision not in _PREC:
+            raise ValueError(f"precision must be one of {sorted(_PREC)}")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise MI355BackendError(f"UNetEngine needs an MI355X device, got {self.device} (no CPU fallback)")
+        self.precision = precision
+        self.cfg = _lib.make_config(dtype=_PREC[precision], **cfg_kwargs)
+        self.L = _lib.lib()
+        inv = param_inventory(self.cfg)
+        host = []
+        for name, shape in inv:
+            if name not in state_dict:
+                raise KeyError(f"state_dict is missing {name}")
+            t = state_dict[name].detach().to("cpu", torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name}: expected shape {shape}, got {tuple(t.shape)}")
+            host.append(t)
+        wbytes = check(self.L.mi355_unet_weight_bytes(C.byref(self.cfg)), "mi355_unet_weight_bytes")
+        with torch.cuda.device(self.device):
+            self.weights = torch.empty(wbytes, dtype=torch.uint8, device=self.device)
+            ptrs = (C.c_void_p * len(host))(*[t.data_ptr() for t in host])
+            handle = C.c_void_p()
+            check(self.L.mi355_unet_create(C.byref(self.cfg), ptrs, len(host), C.c_void_p(self.weights.data_ptr()), wbytes,
+                                           self._stream(), C.byref(handle)), "mi355_unet_create")
+        self.handle = handle
+        self._ws: Optional[torch.Tensor] = None
+        self.in_channels = self.cfg.in_channels
+        self.out_channels = self.cfg.out_channels
+        self.image_size = self.cfg.image_size
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.L.mi355_unet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, batch: int):
+        need = check(self.L.mi355_unet_workspace_bytes(self.handle, batch), "mi355_unet_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return C.c_void_p(self._ws.data_ptr()), self._ws.numel()
+
+    def _chk(self, t: torch.Tensor, name: str, dtype=torch.float32):
+        if not t.is_cuda or t.device != self.device:
+            raise MI355BackendError(f"{name} is on {t.device}, the engine lives on {self.device} (no CPU fallback)")
+        if t.dtype != dtype or not t.is_contiguous():
+            raise TypeError(f"{name} must be contiguous {dtype}")
+        return C.c_void_p(t.data_ptr())
+
+    def _split(self, x, cond):
+        B, Cx, H, W = x.shape
+        if H != self.image_size or W != self.image_size:
+            raise ValueError(f"expected {self.image_size}x{self.image_size} images, got {H}x{W}")
+        Cc = 0
+        if cond is not None:
+            if cond.shape[0] != B or cond.shape[2:] != x.shape[2:]:
+                raise ValueError("condition must match x in batch and spatial size")
+            Cc = cond.shape[1]
+        if Cx + Cc != self.in_channels:
+            raise ValueError(f"x ({Cx}) + condition ({Cc}) channels != in_channels ({self.in_channels})")
+        return B, Cx, Cc
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, cond: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        B, Cx, Cc = self._split(x, cond)
+        if t.shape != (B,):
+            raise ValueError(f"timesteps must have shape ({B},)")
+        if out is None:
+            out = torch.empty(B, self.out_channels, self.image_size, self.image_size, device=self.device, dtype=torch.float32)
+        ws, wsb = self.workspace(B)
+        check(self.L.mi355_unet_forward(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
+                                        Cc, self._chk(t, "timesteps"), self._chk(out, "out"), B, ws, wsb, self._stream()),
+              "mi355_unet_forward")
+        return out
+
+    def stats(self, batch: int):
+        s = _lib.UNetStatsC()
+        check(self.L.mi355_unet_get_stats(self.handle, batch, C.byref(s)))
+        return {"launches": s.launches, "conv_flops": s.conv_flops, "attn_flops": s.attn_flops, "act_bytes": s.act_bytes,
+                "weight_bytes": s.weight_bytes}
+
+    def cfm_euler(self, x: torch.Tensor, t_span: Sequence[float], cond: Optional[torch.Tensor] = None, keep_traj: bool = False,
+                  want_u8: bool = False):
+        """In-place Euler integration of x over t_span (host floats).  Returns (x, traj or None, u8 or None)."""
+        B, Cx, Cc = self._split(x, cond)
+        ts = [float(v) for v in t_span]
+        arr = (C.c_float * len(ts))(*ts)
+        traj = torch.empty((len(ts),) + tuple(x.shape), device=self.device, dtype=torch.float32) if keep_traj else None
+        u8 = torch.empty(x.shape, device=self.device, dtype=torch.uint8) if want_u8 else None
+        ws, wsb = self.workspace(B)
+        check(self.L.mi355_cfm_euler_sample(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
+                                            Cc, arr, len(ts), self._chk(traj, "traj") if traj is not None else None,
+                                            self._chk(u8, "u8", torch.uint8) if u8 is not None else None, B, ws, wsb, self._stream()),
+              "mi355_cfm_euler_sample")
+        return x, traj, u8
+
+    def ddpm_sample(self, x: torch.Tensor, tables: Dict[str, torch.Tensor], *, mode: int, cond: Optional[torch.Tensor] = None,
+                    noise: Optional[torch.Tensor] = None, n_corrector=0, delta=0.1, tmin=1e-5, tmax=1.0, start_fraction=1.0,
+                    noise_condition=True, pad_value=-2.0, none_value=-2.0, seed=0):
+        """In-place reverse-denoising loop.  tables: name -> CPU fp32 tensor [Ns] (DDPM buffers)."""
+        B, Cx = x.shape[:2]
+        if cond is not None and cond.shape != x.shape:
+            raise ValueError("condition must have the shape of x")
+        tb = _lib.DDPMTablesC()
+        keep = []
+        Ns = None
+        fp = C.POINTER(C.c_float)
+        for name, _ in _lib.DDPMTablesC._fields_[1:]:
+            v = tables[name].detach().to("cpu", torch.float32).contiguous()
+            Ns = v.numel() if Ns is None else Ns
+            if v.numel() != Ns:
+                raise ValueError("DDPM tables must all have length Ns")
+            keep.append(v)
+            setattr(tb, name, C.cast(v.data_ptr(), fp))
+        tb.Ns = Ns
+        opt = _lib.DDPMOptionsC(mode, n_corrector, delta, tmin, tmax, start_fraction, int(noise_condition), pad_value, none_value,
+                                int(cond is None), seed)
+        ndraws = 0
+        if noise is not None:
+            if noise.shape[1:] != x.shape:
+                raise ValueError("injected noise must be [n_draws, B, C, H, W]")
+            ndraws = noise.shape[0]
+        ws, wsb = self.workspace(B)
+        check(self.L.mi355_ddpm_sample(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
+                                       C.byref(tb), C.byref(opt), self._chk(noise, "noise") if noise is not None else None, ndraws, B,
+                                       ws, wsb, self._stream()), "mi355_ddpm_sample")
+        return x

@@ -1,0 +1,144 @@
+"""Tensor-level wrappers of the single-op C entry points (PyTorch supplies memory and the stream only).
+
+Every function validates its operands on the host (device, dtype, contiguity, shapes) before a
+hand-written kernel is launched, enqueues on torch's current HIP stream and never synchronises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MI355BackendError, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise MI355BackendError(f"{name} is on {t.device}: the MI355X HIP backend needs device tensors (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _same(a, b, na, nb):
+    if a.shape != b.shape:
+        raise ValueError(f"{na} {tuple(a.shape)} and {nb} {tuple(b.shape)} must have the same shape")
+
+
+class Ops:
+    """Default op table used by the samplers (tests may inject a recording double with the same methods)."""
+
+    def timestep_embedding(self, t, dim, max_period=10000.0):
+        out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float32)
+        check(_lib.lib().mi355_timestep_embedding(_req(t, "t"), t.shape[0], dim, float(max_period), _req(out, "out"), _stream()))
+        return out
+
+    def groupnorm(self, x, gamma, beta, groups=32, eps=1e-5, silu=False):
+        B, Cc = x.shape[:2]
+        hw = x[0, 0].numel()
+        y = torch.empty_like(x)
+        check(_lib.lib().mi355_groupnorm(_req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta"), _req(y, "y"), B, Cc, hw, groups,
+                                         float(eps), int(silu), _stream()))
+        return y
+
+    def euler_step_(self, x, v, dt):
+        _same(x, v, "x", "v")
+        check(_lib.lib().mi355_euler_step(_req(x, "x"), _req(v, "v"), float(dt), x.numel(), _stream()))
+        return x
+
+    def ddpm_step_(self, x, eps, z, c_recip, c_recipm1, coef1, coef2, sigma, philox=None):
+        """z: injected noise tensor, or None; philox: (seed, offset) for device noise; both None = no noise (i == 0)."""
+        _same(x, eps, "x", "eps")
+        zp = _req(z, "z") if z is not None else None
+        if z is not None:
+            _same(x, z, "x", "z")
+        seed, off = philox if philox else (0, 0)
+        check(_lib.lib().mi355_ddpm_step(_req(x, "x"), _req(eps, "eps"), zp, c_recip, c_recipm1, coef1, coef2, sigma,
+                                         int(philox is not None and z is None), seed, off, x.numel(), _stream()))
+        return x
+
+    def corrector_step_(self, x, eps, z, c_recip, c_recipm1, rsm1, dt, delta, philox=None):
+        _same(x, eps, "x", "eps")
+        zp = _req(z, "z") if z is not None else None
+        seed, off = philox if philox else (0, 0)
+        check(_lib.lib().mi355_corrector_step(_req(x, "x"), _req(eps, "eps"), zp, c_recip, c_recipm1, rsm1, dt, delta,
+                                              int(philox is not None and z is None), seed, off, x.numel(), _stream()))
+        return x
+
+    def ddim_step_(self, x, eps, c_recip, c_recipm1, acp_prev):
+        _same(x, eps, "x", "eps")
+        check(_lib.lib().mi355_ddim_step(_req(x, "x"), _req(eps, "eps"), c_recip, c_recipm1, acp_prev, x.numel(), _stream()))
+        return x
+
+    def replace_mask_(self, x, cond, z, pad_value, noisy, sa, sb, philox=None):
+        _same(x, cond, "x", "condition")
+        zp = _req(z, "z") if z is not None else None
+        seed, off = philox if philox else (0, 0)
+        check(_lib.lib().mi355_replace_mask(_req(x, "x"), _req(cond, "condition"), zp, float(pad_value), int(noisy), sa, sb,
+                                            int(philox is not None and z is None), seed, off, x.numel(), _stream()))
+        return x
+
+    def clip_(self, x, lo=-1.0, hi=1.0):
+        check(_lib.lib().mi355_clip(_req(x, "x"), float(lo), float(hi), x.numel(), _stream()))
+        return x
+
+    def quantize_u8(self, x):
+        out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        check(_lib.lib().mi355_quantize_u8(_req(x, "x"), _req(out, "out", torch.uint8), x.numel(), _stream()))
+        return out
+
+    def to_unit_range(self, x):
+        out = torch.empty_like(x)
+        check(_lib.lib().mi355_to_unit_range(_req(x, "x"), _req(out, "out"), x.numel(), _stream()))
+        return out
+
+    def randn(self, shape, device, seed, offset=0):
+        out = torch.empty(shape, device=device, dtype=torch.float32)
+        check(_lib.lib().mi355_randn(_req(out, "out"), int(seed), int(offset), out.numel(), _stream()))
+        return out
+
+    # --- parity-test ops on NCHW fp32 tensors (pack -> MFMA kernel -> unpack) ---
+    def conv2d(self, x, weight, bias=None, stride=1, resample=0, gn=None, gn_silu=False, dtype=_lib.MI355_F32):
+        """weight/bias: CPU fp32 tensors in the reference layout [Co,Ci,k,k]; gn = (gamma, beta) device tensors."""
+        B, Cin, H, W = x.shape
+        Co, Ci, k, _ = weight.shape
+        assert Ci == Cin
+        Hc = H * 2 if resample == 2 else (H // 2 if resample == 3 else H)
+        Wc = W * 2 if resample == 2 else (W // 2 if resample == 3 else W)
+        Ho = (Hc + 2 * (k // 2) - k) // stride + 1
+        Wo = (Wc + 2 * (k // 2) - k) // stride + 1
+        y = torch.empty(B, Co, Ho, Wo, device=x.device, dtype=torch.float32)
+        L = _lib.lib()
+        wsb = L.mi355_op_workspace_bytes(B, max(Cin, Co), max(H * W, Ho * Wo))
+        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        b = bias.detach().to("cpu", torch.float32).contiguous() if bias is not None else None
+        fp = C.POINTER(C.c_float)
+        check(L.mi355_conv2d(_req(x, "x"), C.cast(w.data_ptr(), fp), C.cast(b.data_ptr(), fp) if b is not None else None,
+                             _req(y, "y"), B, Cin, H, W, Co, k, stride, resample,
+                             _req(gn[0], "gamma") if gn else None, _req(gn[1], "beta") if gn else None, int(gn_silu), dtype,
+                             C.c_void_p(ws.data_ptr()), wsb, _stream()), "mi355_conv2d")
+        return y
+
+    def qkv_attention(self, qkv, heads, new_order=False, dtype=_lib.MI355_F32):
+        B, width, T = qkv.shape
+        ch = width // (3 * heads)
+        out = torch.empty(B, heads * ch, T, device=qkv.device, dtype=torch.float32)
+        L = _lib.lib()
+        wsb = L.mi355_op_workspace_bytes(B, width, T)
+        ws = torch.empty(wsb, device=qkv.device, dtype=torch.uint8)
+        check(L.mi355_qkv_attention(_req(qkv, "qkv"), _req(out, "out"), B, heads, ch, T, int(new_order), dtype,
+                                    C.c_void_p(ws.data_ptr()), wsb, _stream()), "mi355_qkv_attention")
+        return out
+
+
+default_ops = Ops()

@@ -1,0 +1,126 @@
+"""Stand-ins for the two un-vendored third-party front-ends the reference's cifar10/ and mnist/ scripts
+import, so those scripts' sampler call sites work unchanged on the MI355X backend:
+
+  torchcfm.models.unet.unet.UNetModelWrapper   (cifar10/train_cifar10.py:22,92-101; compute_fid.py:16,39-48)
+  torchdyn.core.NeuralODE                      (cifar10/utils_cifar.py:4,34-39; compute_fid.py:14,69-70)
+
+Neither package is in /root/reference (versions unpinned; weight URLs point at torchcfm 1.0.4); their
+published behaviour is restated from the reference's call sites: constructor keywords, the
+`model(t, x, y=None)` call convention with scalar or [B] `t`, and `trajectory(x, t_span)` returning all
+len(t_span) states of a fixed-step Euler integration.  `InPaintModelWrapper` / `SuperResModelWrapper` are
+the author's unpublished torchcfm edits (mnist/train_mnist.py:34, train_mnist_hy.py:36); their semantics
+(channel-concat of the condition / of the bilinearly upsampled low-res image) are inferred from the
+keyword arguments at mnist/utils_mnist.py:97 and mnist/utils_mnist_hy.py:82 - "parity unpinned".
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from image_diffusion.unet import UNetModel
+from mi355.ops import default_ops
+
+
+def _default_mult(image_size):
+    table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4), 32: (1, 2, 2, 2),
+             28: (1, 2, 2)}
+    if image_size not in table:
+        raise ValueError(f"unsupported image size: {image_size}")
+    return table[image_size]
+
+
+class UNetModelWrapper(UNetModel):
+    """torchcfm UNetModelWrapper: dim=(C,H,W), attention_resolutions as a string of resolutions."""
+
+    def __init__(self, dim, num_channels, num_res_blocks, channel_mult=None, learn_sigma=False, class_cond=False, num_classes=None,
+                 use_checkpoint=False, attention_resolutions="16", num_heads=1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, dropout=0, resblock_updown=False, use_fp16=False, use_new_attention_order=False,
+                 in_channels: Optional[int] = None, precision: Optional[str] = None):
+        image_size = dim[-1]
+        channel_mult = _default_mult(image_size) if channel_mult is None else tuple(channel_mult)
+        attention_ds = tuple(image_size // int(res) for res in str(attention_resolutions).split(","))
+        if class_cond:
+            raise NotImplementedError("class-conditional sampling is not used by the reference's samplers")
+        super().__init__(image_size=image_size, in_channels=dim[0] if in_channels is None else in_channels,
+                         model_channels=num_channels, out_channels=(dim[0] if not learn_sigma else dim[0] * 2),
+                         num_res_blocks=num_res_blocks, attention_resolutions=attention_ds, dropout=dropout,
+                         channel_mult=channel_mult, num_classes=None, use_checkpoint=use_checkpoint, use_fp16=use_fp16,
+                         num_heads=num_heads, num_head_channels=num_head_channels, num_heads_upsample=num_heads_upsample,
+                         use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
+                         use_new_attention_order=use_new_attention_order, precision=precision)
+
+    def _t(self, t, x):
+        t = torch.as_tensor(t, device=x.device).float()
+        while t.dim() > 1:
+            t = t[:, 0]
+        if t.dim() == 0:
+            t = t.repeat(x.shape[0])
+        return t
+
+    @torch.no_grad()
+    def forward(self, t, x, y=None, *args, **kwargs):
+        return super().forward(x, self._t(t, x))
+
+
+class InPaintModelWrapper(UNetModelWrapper):
+    """model.forward(x, t, con=con): the -2-sentinel condition image is concatenated on the channel axis."""
+
+    def __init__(self, dim, *a, **kw):
+        super().__init__(dim, *a, in_channels=2 * dim[0], **kw)
+
+    @torch.no_grad()
+    def forward(self, x, t, con=None, **kwargs):
+        eng = self.engine(x.device)
+        return eng.forward(x.float().contiguous(), self._t(t, x).contiguous(), cond=con.float().contiguous())
+
+
+class SuperResModelWrapper(UNetModelWrapper):
+    """model.forward(x, t, low_res=low_res): low_res is bilinearly upsampled to x's size and concatenated
+    (the guided-diffusion SuperResModel convention)."""
+
+    def __init__(self, dim, *a, **kw):
+        super().__init__(dim, *a, in_channels=2 * dim[0], **kw)
+
+    @torch.no_grad()
+    def forward(self, x, t, low_res=None, **kwargs):
+        up = F.interpolate(low_res, (x.shape[2], x.shape[3]), mode="bilinear")
+        eng = self.engine(x.device)
+        return eng.forward(x.float().contiguous(), self._t(t, x).contiguous(), cond=up.float().contiguous())
+
+
+class NeuralODE:
+    """torchdyn.core.NeuralODE front-end, fixed-step Euler only (the adaptive dopri5 path is a 'next' row).
+
+    trajectory(x, t_span) -> Tensor[len(t_span), *x.shape].  When the vector field is a UNetModelWrapper the whole
+    integration runs inside libmi355_sampler (mi355_cfm_euler_sample); any other callable f(t, x[, args]) is driven
+    step by step from the host with the HIP Euler-update kernel."""
+
+    def __init__(self, vector_field, solver="euler", sensitivity="adjoint", atol=1e-4, rtol=1e-4, **kwargs):
+        if solver != "euler":
+            raise NotImplementedError(
+                f"solver={solver!r}: only the fixed-step Euler path is built (adaptive dopri5 is a 'next' row, SURVEY.md 8f)")
+        self.vf = vector_field
+        self.solver = solver
+
+    def to(self, *a, **k):
+        return self
+
+    @torch.no_grad()
+    def trajectory(self, x, t_span):
+        ts = [float(v) for v in torch.as_tensor(t_span).detach().cpu().tolist()]
+        x = x.detach().clone().float().contiguous()
+        if type(self.vf) is UNetModelWrapper and x.is_cuda:
+            _, traj, _ = self.vf.engine(x.device).cfm_euler(x, ts, keep_traj=True)
+            return traj
+        out = [x.clone()]
+        for k in range(len(ts) - 1):
+            t = torch.tensor(ts[k], device=x.device, dtype=torch.float32)
+            try:
+                v = self.vf(t, x)
+            except TypeError:
+                v = self.vf(t, x, None)  # torchdyn passes `args` to 3-argument vector fields (mnist/utils_mnist2.py:120)
+            default_ops.euler_step_(x, v.float().contiguous(), ts[k + 1] - ts[k])
+            out.append(x.clone())
+        return torch.stack(out)

@@ -1,0 +1,47 @@
+"""Drop-in for the reference's `cifar10/utils_cifar.py` (generate_samples / ema / infiniteloop), MI355X backend.
+
+`generate_samples` keeps the reference signature and file naming (cifar10/utils_cifar.py:13-44): 64 samples,
+99 Euler steps over linspace(0, 1, 100), clip(-1,1)/2+0.5, 8x8 PNG grid.  The integration runs inside
+libmi355_sampler (one C call), the post-processing is the fused HIP kernel.
+"""
+import torch
+
+from mi355.imageio import save_image
+from mi355.ops import default_ops
+from torchcfm_compat import NeuralODE
+
+use_cuda = torch.cuda.is_available()
+device = torch.device("cuda" if use_cuda else "cpu")
+
+
+def generate_samples(model, parallel, savedir, step, net_="normal"):
+    """Save 64 generated images (8 x 8) for sanity check along training (cifar10/utils_cifar.py:13-44)."""
+    model.eval()
+    model_ = model
+    if parallel:
+        # the reference unwraps nn.DataParallel to a single device for torchdyn (utils_cifar.py:30-32)
+        model_ = model_.module.to(device)
+    node_ = NeuralODE(model_, solver="euler", sensitivity="adjoint")
+    with torch.no_grad():
+        traj = node_.trajectory(
+            torch.randn(64, 3, 32, 32, device=device),
+            t_span=torch.linspace(0, 1, 100, device=device),
+        )
+        traj = default_ops.to_unit_range(traj[-1, :].view([-1, 3, 32, 32]).contiguous())  # clip(-1, 1) / 2 + 0.5
+    save_image(traj, savedir + f"{net_}_generated_FM_images_step_{step}.png", nrow=8)
+    model.train()
+
+
+def ema(source, target, decay):
+    """cifar10/utils_cifar.py:47-53 (host-side parameter plumbing, used by the training script)."""
+    source_dict = source.state_dict()
+    target_dict = target.state_dict()
+    for key in source_dict.keys():
+        target_dict[key].data.copy_(target_dict[key].data * decay + source_dict[key].data * (1 - decay))
+
+
+def infiniteloop(dataloader):
+    """cifar10/utils_cifar.py:56-59."""
+    while True:
+        for x, y in iter(dataloader):
+            yield x

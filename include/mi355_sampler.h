@@ -1,0 +1,204 @@
+/*
+ * mi355_sampler.h - C ABI of libmi355_sampler.so (gfx950 / MI355X only).
+ *
+ * The reference (VladimirRadenkovic/Image-inpainting-and-Super-Resolution-...) is pure Python and has
+ * no FFI layer; the drop-in boundary is a set of Python call signatures.  This
+ * header is the C ABI that the package's Python mirror of those signatures binds with ctypes
+ * (see INTEGRATION.md).  Each entry point cites the reference code it replaces, paths relative to
+ * /root/reference, "AD/" = "amortised diffusion/".
+ *
+ * Conventions
+ *   - every `const float* x`-style data pointer is a DEVICE pointer owned by the caller (the PyTorch
+ *     allocator), contiguous, NCHW fp32 at the boundary;  host pointers are named *_host;
+ *   - `stream` is a hipStream_t passed as void*; functions only enqueue work on it, they never
+ *     synchronise and never allocate device memory (workspaces are sized by *_bytes() and passed in);
+ *   - return value 0 = ok, negative = error; the message is in mi355_last_error() (thread local);
+ *   - no C++ exceptions cross the ABI; no hidden globals besides the error string.
+ */
+#ifndef MI355_SAMPLER_H
+#define MI355_SAMPLER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_ERR_ARG (-1)
+#define MI355_ERR_SHAPE (-2)
+#define MI355_ERR_HIP (-3)
+#define MI355_ERR_UNSUPPORTED (-4)
+
+/* compute type of the contraction path */
+#define MI355_F32 0  /* fp32 storage, exact f32 MFMA (v_mfma_f32_16x16x4_f32): tight-parity mode   */
+#define MI355_BF16 1 /* bf16 storage + bf16 MFMA, fp32 accumulate; GN stats / softmax / x state fp32 */
+
+int mi355_version(void);
+const char* mi355_last_error(void);
+
+/* ---- U-Net (AD/image_diffusion/unet.py:490-728 UNetModel; == torchcfm UNetModelWrapper) ---------- */
+
+typedef struct mi355_unet_config {
+  int32_t image_size;
+  int32_t in_channels;
+  int32_t model_channels;
+  int32_t out_channels;
+  int32_t num_res_blocks;
+  int32_t n_attention_ds;
+  int32_t attention_ds[8];  /* downsample rates with attention (UNetModel.attention_resolutions)   */
+  int32_t n_channel_mult;
+  int32_t channel_mult[8];  /* integer multipliers only                                            */
+  int32_t conv_resample;
+  int32_t num_heads;
+  int32_t num_head_channels;
+  int32_t num_heads_upsample;
+  int32_t use_scale_shift_norm;
+  int32_t resblock_updown;
+  int32_t use_new_attention_order;
+  int32_t dtype; /* MI355_F32 | MI355_BF16 */
+} mi355_unet_config;
+
+typedef struct mi355_unet mi355_unet; /* opaque */
+
+/* Parameter inventory in the reference's state_dict order (unet.py:564-706).  Returns the count,
+ * or fills name/shape for parameter `index`.  The Python side feeds tensors in exactly this order. */
+int mi355_unet_param_count(const mi355_unet_config* cfg);
+int mi355_unet_param_info(const mi355_unet_config* cfg, int index, char* name, int name_cap, int64_t shape[4], int* ndim);
+
+/* Bytes of device memory the packed weights need (caller allocates, 256-byte aligned). */
+int64_t mi355_unet_weight_bytes(const mi355_unet_config* cfg);
+
+/* Build the layer plan and pack `params_host[i]` (fp32, reference layouts: conv [Co,Ci,k,k],
+ * qkv/proj [Co,Ci,1], linear [out,in]) into kernel layouts inside `dev_weights` (async on stream). */
+int mi355_unet_create(const mi355_unet_config* cfg, const float* const* params_host, int n_params, void* dev_weights,
+                      int64_t dev_weights_bytes, void* stream, mi355_unet** out);
+void mi355_unet_destroy(mi355_unet* net);
+
+int64_t mi355_unet_workspace_bytes(const mi355_unet* net, int batch);
+
+/* UNetModel.forward(x, timesteps) (unet.py:708-728).  x: [B, Cx, H, W]; cond: NULL or [B, Cc, H, W]
+ * with Cx + Cc == in_channels (the Amortized sampler's channel concat, AD/image_diffusion/sampling.py:39,
+ * is folded into the first conv's gather); t: float[B]; out: [B, out_channels, H, W]. */
+int mi355_unet_forward(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels,
+                       const float* t, float* out, int batch, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Launch/traffic counters of the last forward (host side bookkeeping, for bench.py's roofline). */
+typedef struct mi355_unet_stats {
+  int64_t launches;
+  double conv_flops;      /* 2*MAC of all conv/1x1/linear contractions        */
+  double attn_flops;      /* 2*MAC of QK^T and PV                             */
+  double act_bytes;       /* algorithmic activation bytes (in + out of each contraction op) */
+  double weight_bytes;    /* packed weight bytes                              */
+} mi355_unet_stats;
+int mi355_unet_get_stats(const mi355_unet* net, int batch, mi355_unet_stats* out);
+
+/* ---- sampler loops ------------------------------------------------------------------------------ */
+
+/* Fixed-step Euler CFM sampler: x_{k+1} = x_k + (t_{k+1}-t_k) * model(t_k, x_k)
+ * (torchdyn NeuralODE(solver="euler").trajectory as called at cifar10/compute_fid.py:69-79,
+ *  cifar10/utils_cifar.py:34-39, mnist/utils_mnist2.py:125-134).
+ * x: in/out [B, Cx, H, W].  traj: NULL or [n_t, B, Cx, H, W] (all states, as the reference returns).
+ * u8_out: NULL or uint8 [B, Cx, H, W] = (x*127.5+128).clip(0,255) (cifar10/compute_fid.py:87). */
+int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const float* cond, int cond_channels,
+                           const float* t_span_host, int n_t, float* traj, uint8_t* u8_out, int batch,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* per-step scalars of the DDPM tables (AD/image_diffusion/sde_diffusion.py:127-167), host arrays of length Ns */
+typedef struct mi355_ddpm_tables {
+  int32_t Ns;
+  const float* sqrt_recip_alphas_cumprod;
+  const float* sqrt_recipm1_alphas_cumprod;
+  const float* posterior_mean_coef1;
+  const float* posterior_mean_coef2;
+  const float* posterior_log_variance_clipped;
+  const float* sqrt_alphas_cumprod;
+  const float* sqrt_one_minus_alphas_cumprod;
+  const float* recip_sqrt_m1_alphas_cumprod;
+  const float* alphas_cumprod_prev;
+} mi355_ddpm_tables;
+
+#define MI355_DDPM_PRIOR 0       /* get_prior_sample_fn                 sampling.py:50-75   */
+#define MI355_DDPM_AMORTIZED 1   /* get_conditional_sample_fn[Amortized] sampling.py:80-133  */
+#define MI355_DDPM_REPLACEMENT 2 /* get_conditional_sample_fn[Replacement] sampling.py:209-260 */
+#define MI355_DDIM 3             /* build-defined deterministic DDIM(eta=0) on the same tables */
+
+typedef struct mi355_ddpm_options {
+  int32_t mode;
+  int32_t n_corrector;      /* Langevin corrector steps per predictor step (sampling.py:113-121) */
+  float delta;              /* corrector step size                                                */
+  float tmin, tmax;         /* DDPM.tmin / tmax (sde_diffusion.py:130-132)                        */
+  float start_fraction;     /* Replacement: replace while i < int(Ns*start_fraction)              */
+  int32_t noise_condition;  /* Replacement: q_sample the condition (1) or use it as is (0)        */
+  float pad_value;          /* Replacement: mask sentinel (-2)  likelihoods.py:55-56              */
+  float none_value;         /* Amortized: value of likelihood.none_like (-2 painting, 0 hyperres) */
+  int32_t cond_is_none;     /* Amortized prior (cond == NULL): feed none_like as the condition    */
+  uint64_t seed;            /* device Philox seed when noise == NULL                              */
+} mi355_ddpm_options;
+
+/* Reverse-denoising loop i = Ns-1..0.  x: in/out [B, C, H, W] (xT -> x0, clipped to [-1,1]).
+ * cond: NULL or [B, C, H, W].  noise: NULL (device Philox) or the injected draws, one [B,C,H,W]
+ * tensor per torch.randn_like call of the reference, in call order. */
+int mi355_ddpm_sample(mi355_unet* net, float* x, int channels, const float* cond, const mi355_ddpm_tables* tables,
+                      const mi355_ddpm_options* opt, const float* noise, int64_t n_noise_draws, int batch,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- single ops (used by the Python mirror for arbitrary eps_model callables, and by the tests) --- */
+
+/* timestep_embedding (AD/image_diffusion/nn.py:97-115): t[B] -> out[B, dim] */
+int mi355_timestep_embedding(const float* t, int batch, int dim, float max_period, float* out, void* stream);
+
+/* GroupNorm32 (+ optional SiLU) on NCHW fp32 (nn.py:11-13,87-94), standalone op for parity tests */
+int mi355_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int batch, int channels, int hw,
+                    int groups, float eps, int silu, void* stream);
+
+/* x += dt * v  (Euler update) */
+int mi355_euler_step(float* x, const float* v, float dt, int64_t n, void* stream);
+
+/* DDPM ancestral step (sampling.py:59-67 + sde_diffusion.py:220-237), elementwise over n values:
+ *   x0 = clip(c_recip*x - c_recipm1*eps, -1, 1); mean = coef1*x0 + coef2*x; x <- mean + sigma*z
+ * z == NULL and use_philox == 0 means "no noise" (i == 0). */
+int mi355_ddpm_step(float* x, const float* eps, const float* z, float c_recip, float c_recipm1, float coef1, float coef2,
+                    float sigma, int use_philox, uint64_t seed, uint64_t offset, int64_t n, void* stream);
+
+/* Langevin corrector (sampling.py:113-121): x += 0.5*dt*delta*score + sqrt(dt*delta)*z,
+ * score = -recip_sqrt_m1 * clip(c_recip*x - c_recipm1*eps, -1, 1) */
+int mi355_corrector_step(float* x, const float* eps, const float* z, float c_recip, float c_recipm1, float recip_sqrt_m1,
+                         float dt, float delta, int use_philox, uint64_t seed, uint64_t offset, int64_t n, void* stream);
+
+/* DDIM(eta=0) step on the same tables (build-defined extension) */
+int mi355_ddim_step(float* x, const float* eps, float c_recip, float c_recipm1, float acp_prev, int64_t n, void* stream);
+
+/* Replacement mask (sampling.py:225-232): x = where(cond == pad, x, noisy ? sa*cond + sb*z : cond) */
+int mi355_replace_mask(float* x, const float* cond, const float* z, float pad_value, int noisy, float sa, float sb,
+                       int use_philox, uint64_t seed, uint64_t offset, int64_t n, void* stream);
+
+/* clip(x, lo, hi) in place, NaN-propagating like torch.clip (sampling.py:13-14) */
+int mi355_clip(float* x, float lo, float hi, int64_t n, void* stream);
+/* (x*127.5+128).clip(0,255).to(uint8)  cifar10/compute_fid.py:87 */
+int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream);
+/* x.clip(-1,1)/2 + 0.5  cifar10/utils_cifar.py:40-41 */
+int mi355_to_unit_range(const float* x, float* out, int64_t n, void* stream);
+/* N(0,1) fill from the device Philox4x32-10 stream (seed, offset) */
+int mi355_randn(float* out, uint64_t seed, uint64_t offset, int64_t n, void* stream);
+
+/* Standalone conv / attention ops on NCHW fp32 tensors for parity tests of the HIP kernels
+ * (pack -> implicit-GEMM MFMA kernel -> unpack; `workspace` from mi355_op_workspace_bytes). */
+int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw);
+/* Conv2d k in {1,3}, stride in {1,2}, padding k/2 - w_host [Co,Ci,k,k], bias_host [Co] are HOST pointers.
+ * resample: 0 none, 2 nearest x2 upsample of the input (unet.py:185-212), 3 2x2 average pool of the input.
+ * Optional fused prologue GroupNorm32(gamma, beta) [+ SiLU] on the input (gn_gamma/gn_beta device
+ * pointers or NULL), i.e. the ResBlock in_layers / out_layers (unet.py:283-286,306-311).
+ * Synchronises the stream (test op: the packed weights are staged from a temporary host buffer). */
+int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, float* y, int batch, int cin, int h, int w,
+                 int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
+                 int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+/* QKVAttentionLegacy / QKVAttention (unet.py:424-487): qkv [B, 3*H*ch, T] -> out [B, H*ch, T] */
+int mi355_qkv_attention(const float* qkv, float* out, int batch, int heads, int head_channels, int length, int new_order,
+                        int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_SAMPLER_H */
