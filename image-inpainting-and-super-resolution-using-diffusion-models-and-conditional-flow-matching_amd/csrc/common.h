@@ -29,9 +29,11 @@ template <> struct Elem<bf16> {
 };
 
 // 16-B fragment <-> float conversions
+// NB: never __builtin_bit_cast a single element of an ext-vector lvalue (`bit_cast(float, v[i])` reads element 0
+// for every i with hipcc 7.2); cast the whole vector and index the result.
 __device__ __forceinline__ void frag_to_float(const u32x4& v, float (&f)[4], float) {
-  f[0] = __builtin_bit_cast(float, v[0]); f[1] = __builtin_bit_cast(float, v[1]);
-  f[2] = __builtin_bit_cast(float, v[2]); f[3] = __builtin_bit_cast(float, v[3]);
+  const f32x4 t = __builtin_bit_cast(f32x4, v);
+  f[0] = t[0]; f[1] = t[1]; f[2] = t[2]; f[3] = t[3];
 }
 __device__ __forceinline__ void frag_to_float(const u32x4& v, float (&f)[8], bf16) {
 #pragma unroll
@@ -41,10 +43,7 @@ __device__ __forceinline__ void frag_to_float(const u32x4& v, float (&f)[8], bf1
   }
 }
 __device__ __forceinline__ u32x4 float_to_frag(const float (&f)[4], float) {
-  u32x4 v;
-  v[0] = __builtin_bit_cast(uint32_t, f[0]); v[1] = __builtin_bit_cast(uint32_t, f[1]);
-  v[2] = __builtin_bit_cast(uint32_t, f[2]); v[3] = __builtin_bit_cast(uint32_t, f[3]);
-  return v;
+  return __builtin_bit_cast(u32x4, f32x4{f[0], f[1], f[2], f[3]});
 }
 __device__ __forceinline__ u32x4 float_to_frag(const float (&f)[8], bf16) {
   bf16x8 b;
@@ -60,9 +59,11 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, float) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[i]), __builtin_bit_cast(float, b[i]), acc, 0, 0, 0);
+  const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
 }
 
 template <bool FAST> __device__ __forceinline__ float silu_f(float v) {

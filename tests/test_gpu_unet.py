@@ -1,0 +1,214 @@
+"""GPU parity of the whole U-Net forward and of the sampler loops, through the product's Python boundary
+(image_diffusion / torchcfm_compat / utils_*), against reference-generated goldens and the CPU oracle.
+
+Tolerances (stated, per north_star):
+  fp32 mode  - exact-f32 MFMA, differs from the reference only by summation order: 2e-4 rel / 5e-5 abs per forward;
+  bf16 mode  - bf16 storage + bf16 MFMA with fp32 accumulate: error is reported and bounded relative to the output scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+from mi355.synth import rand_uniform, randn, synth_state_dict
+from oracle import cfm_ref, ddpm_ref, unet_ref
+from tests.test_oracle_golden import UNETS, NoiseLog, cfg_from_json
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(cfg, seed, precision):
+    from image_diffusion.unet import UNetModel, param_shapes
+
+    net = UNetModel(image_size=cfg.image_size, in_channels=cfg.in_channels, model_channels=cfg.model_channels,
+                    out_channels=cfg.out_channels, num_res_blocks=cfg.num_res_blocks, attention_resolutions=cfg.attention_resolutions,
+                    channel_mult=cfg.channel_mult, conv_resample=cfg.conv_resample, num_heads=cfg.num_heads,
+                    num_head_channels=cfg.num_head_channels, num_heads_upsample=cfg.num_heads_upsample,
+                    use_scale_shift_norm=cfg.use_scale_shift_norm, resblock_updown=cfg.resblock_updown,
+                    use_new_attention_order=cfg.use_new_attention_order, precision=precision)
+    sd = synth_state_dict(param_shapes(cfg), seed)
+    net.load_state_dict(sd)
+    return net.to(DEV), sd
+
+
+@pytest.mark.parametrize("name", UNETS)
+def test_unet_forward_fp32(golden, name):
+    g = golden("unet_" + name)
+    cfg = cfg_from_json(g.json("config"))
+    net, _ = build(cfg, int(g["seed"]), "fp32")
+    y = net(g.t("x").to(DEV), g.t("t").to(DEV)).cpu()
+    torch.testing.assert_close(y, g.t("y"), rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("name", UNETS)
+def test_unet_forward_bf16(golden, name):
+    g = golden("unet_" + name)
+    cfg = cfg_from_json(g.json("config"))
+    net, _ = build(cfg, int(g["seed"]), "bf16")
+    y = net(g.t("x").to(DEV), g.t("t").to(DEV)).cpu()
+    ref = g.t("y")
+    scale = ref.abs().max().item()
+    err = (y - ref).abs().max().item()
+    rms = ((y - ref) ** 2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
+    print(f"{name}: bf16 max|err| {err:.3e} (out scale {scale:.3f}), rel rms {rms:.3e}")
+    assert err < 0.04 * scale and rms < 0.02
+
+
+def test_state_dict_layout_matches_engine(golden):
+    """Python param_shapes (module builder) and the C++ plan builder agree, name by name."""
+    from image_diffusion.unet import param_shapes
+    from mi355 import _lib
+    from mi355.engine import param_inventory
+
+    for name in UNETS:
+        cfg = cfg_from_json(golden("unet_" + name).json("config"))
+        c = _lib.make_config(image_size=cfg.image_size, in_channels=cfg.in_channels, model_channels=cfg.model_channels,
+                             out_channels=cfg.out_channels, num_res_blocks=cfg.num_res_blocks, attention_ds=cfg.attention_resolutions,
+                             channel_mult=cfg.channel_mult, conv_resample=cfg.conv_resample, num_heads=cfg.num_heads,
+                             num_head_channels=cfg.num_head_channels, use_scale_shift_norm=cfg.use_scale_shift_norm,
+                             resblock_updown=cfg.resblock_updown, use_new_attention_order=cfg.use_new_attention_order)
+        assert param_inventory(c) == list(param_shapes(cfg).items())
+
+
+def test_batch_independence_and_large_batch():
+    """Per-sample independence (what makes batch sharding exact): image k of a 37-image batch == the same image alone."""
+    cfg = unet_ref.UNetConfig(16, 3, 32, 3, 1, (2,), channel_mult=(1, 2), num_heads=2)
+    net, _ = build(cfg, 1003, "fp32")
+    x = randn(99, 37, 3, 16, 16).to(DEV)
+    t = torch.linspace(0, 1, 37).to(DEV)
+    y = net(x, t)
+    for k in (0, 5, 36):
+        yk = net(x[k:k + 1].contiguous(), t[k:k + 1].contiguous())
+        torch.testing.assert_close(y[k:k + 1], yk, rtol=1e-5, atol=1e-6)
+
+
+def _tiny(in_ch, out_ch, seed, precision):
+    cfg = unet_ref.UNetConfig(16, in_ch, 32, out_ch, 1, (2,), channel_mult=(1, 2), num_heads=2)
+    net, sd = build(cfg, seed, precision)
+    return cfg, net, sd
+
+
+def test_euler_trajectory_golden(golden):
+    """torchcfm-convention model(t, x) + NeuralODE(euler).trajectory against the reference-driven golden."""
+    from torchcfm_compat import NeuralODE, UNetModelWrapper
+
+    g = golden("euler_tiny")
+    net = UNetModelWrapper(dim=(3, 16, 16), num_channels=32, num_res_blocks=1, channel_mult=(1, 2), num_heads=2,
+                           attention_resolutions="8", precision="fp32")
+    from image_diffusion.unet import param_shapes
+    net.load_state_dict(synth_state_dict(param_shapes(net), int(g["seed"])))
+    net.to(DEV)
+    traj = NeuralODE(net, solver="euler").trajectory(g.t("x0").to(DEV), torch.linspace(0, 1, 6))
+    torch.testing.assert_close(traj.cpu(), g.t("traj"), rtol=5e-4, atol=5e-5)
+    from mi355.ops import default_ops
+    u8 = default_ops.quantize_u8(traj[-1].contiguous()).cpu()
+    assert (u8.int() - g.t("u8").int()).abs().max() <= 1
+    # generic (host-driven) path with an arbitrary callable gives the same trajectory
+    traj2 = NeuralODE(lambda t, x: net(t, x), solver="euler").trajectory(g.t("x0").to(DEV), torch.linspace(0, 1, 6))
+    torch.testing.assert_close(traj2, traj, rtol=1e-5, atol=1e-6)
+
+
+SAMPLER_TOL = dict(rtol=2e-3, atol=1e-3)  # 25 sequential fp32 U-Net calls through an x0 predictor with gain up to 2e3
+
+
+def test_ddpm_samplers_golden(golden):
+    from image_diffusion import sampling
+    from image_diffusion.conditioning import Amortized, Replacement
+    from image_diffusion.likelihoods import InPainting
+    from image_diffusion.sde_diffusion import DDPM
+
+    g = golden("samplers_tiny")
+    Ns = int(g["Ns"])
+    ddpm = DDPM(Ns)
+    lik = InPainting(patch_size=6, pad_value=-2)
+    _, net1, _ = _tiny(1, 1, 1001, "fp32")
+    _, net2, _ = _tiny(2, 1, 1002, "fp32")
+
+    def draws(tag, shape):
+        base, k = int(g[f"{tag}/noise_base"]), int(g[f"{tag}/draws"]) if f"{tag}/draws" in g.keys() else Ns - 1
+        return [randn(base + j, *shape) for j in range(k)]
+
+    for fast in (True, False):
+        mk = (lambda net: sampling.make_eps_model(net, ddpm)) if fast else (lambda net: (lambda xi, i: net(xi, 1.0 * i / ddpm.Ns)))
+        eps1, eps2 = mk(net1), mk(net2)
+        shape = tuple(g["prior/xT"].shape)
+        with sampling.injected_noise(draws("prior", shape)):
+            x0 = sampling.get_prior_sample_fn(eps1, ddpm, Replacement(0.1, 1.0, True, 0), lik)(g.t("prior/xT").to(DEV))
+        torch.testing.assert_close(x0.cpu(), g.t("prior/x0"), **SAMPLER_TOL)
+
+        for tag, nc in (("amortized", 0), ("amortized_corr1", 1)):
+            with sampling.injected_noise(draws(tag, shape)):
+                fn = sampling.get_conditional_sample_fn(eps2, ddpm, Amortized(0.9, nc, 0.1), lik)
+                x0 = fn(g.t(f"{tag}/xT").to(DEV), g.t(f"{tag}/cond").to(DEV))
+            torch.testing.assert_close(x0.cpu(), g.t(f"{tag}/x0"), **SAMPLER_TOL)
+
+        with sampling.injected_noise(draws("amortized_prior", shape)):
+            x0 = sampling.get_prior_sample_fn(eps2, ddpm, Amortized(0.9, 0, 0.1), lik)(g.t("amortized_prior/xT").to(DEV))
+        torch.testing.assert_close(x0.cpu(), g.t("amortized_prior/x0"), **SAMPLER_TOL)
+
+        for tag in ("replacement_noise", "replacement_clean", "replacement_half"):
+            cond = Replacement(0.1, float(g[f"{tag}/start_fraction"]), bool(g[f"{tag}/noisy"]), 0)
+            with sampling.injected_noise(draws(tag, shape)):
+                x0 = sampling.get_conditional_sample_fn(eps1, ddpm, cond, lik)(g.t(f"{tag}/xT").to(DEV), g.t(f"{tag}/cond").to(DEV))
+            torch.testing.assert_close(x0.cpu(), g.t(f"{tag}/x0"), **SAMPLER_TOL)
+
+
+def test_ddpm_ns20_is_nan():
+    """Known-answer quirk: DDPM(20) => NaN samples, as in the reference (SURVEY finding 4)."""
+    from image_diffusion import sampling
+    from image_diffusion.conditioning import Replacement
+    from image_diffusion.likelihoods import InPainting
+    from image_diffusion.sde_diffusion import DDPM
+
+    ddpm = DDPM(20)
+    _, net1, _ = _tiny(1, 1, 1001, "fp32")
+    fn = sampling.get_prior_sample_fn(sampling.make_eps_model(net1, ddpm), ddpm, Replacement(0.1, 1.0, True, 0), InPainting(6, -2))
+    x0 = fn(randn(3, 2, 1, 16, 16).to(DEV))
+    assert torch.isnan(x0).all()
+
+
+def test_ddim_extension_vs_oracle():
+    from image_diffusion import sampling
+    from image_diffusion.sde_diffusion import DDPM
+
+    Ns = 25
+    cfg, net, sd = _tiny(2, 1, 1002, "fp32")
+    ddpm = DDPM(Ns)
+    xT = randn(5, 2, 1, 16, 16)
+    cond = rand_uniform(6, -1, 1, 2, 1, 16, 16)
+    cond[:, :, 4:12, 4:12] = -2.0
+    ref = ddpm_ref.ddim_sample(ddpm_ref.make_eps_model(lambda x, t: unet_ref.unet_forward(sd, cfg, x, t), Ns), Ns, xT, cond)
+    got = sampling.get_ddim_sample_fn(sampling.make_eps_model(net, ddpm), ddpm)(xT.to(DEV), cond.to(DEV))
+    torch.testing.assert_close(got.cpu(), ref, **SAMPLER_TOL)
+
+
+def test_cifar_cfm_euler_bf16_vs_fp32_oracle():
+    """BASELINE config 2 at a CPU-feasible size: CIFAR U-Net, Euler steps, bf16 vs the fp32 CPU oracle."""
+    from compute_fid import build_model
+    from image_diffusion.unet import param_shapes
+
+    steps, B = 10, 2
+    net = build_model(128, DEV, precision="bf16")
+    sd = synth_state_dict(param_shapes(net), 1234)
+    net.load_state_dict(sd)
+    cfg = unet_ref.UNetConfig(32, 3, 128, 3, 2, (2,), channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
+    x0 = randn(42, B, 3, 32, 32)
+    ref = cfm_ref.euler_trajectory(unet_ref.model_fn(sd, cfg), x0, torch.linspace(0, 1, steps + 1), keep_all=False)
+    x = x0.to(DEV).clone()
+    _, _, u8 = net.engine(DEV).cfm_euler(x, torch.linspace(0, 1, steps + 1).tolist(), want_u8=True)
+    err = (x.cpu() - ref).abs()
+    print(f"cifar bf16 {steps}-step Euler: max|err| {err.max():.3e} rms {err.pow(2).mean().sqrt():.3e}; |x| max {ref.abs().max():.2f}")
+    assert err.max() < 0.08 and err.pow(2).mean().sqrt() < 0.015
+    assert (u8.cpu().int() - cfm_ref.to_uint8(ref).int()).abs().float().mean() < 1.0
+    net.set_precision("fp32")
+    x = x0.to(DEV).clone()
+    net.engine(DEV).cfm_euler(x, torch.linspace(0, 1, steps + 1).tolist())
+    torch.testing.assert_close(x.cpu(), ref, rtol=1e-3, atol=2e-4)
+
+
+def test_cpu_tensors_fail_loudly():
+    from mi355._lib import MI355BackendError
+
+    _, net, _ = _tiny(1, 1, 1001, "fp32")
+    with pytest.raises(MI355BackendError):
+        net(torch.zeros(1, 1, 16, 16), torch.zeros(1))
