@@ -73,6 +73,31 @@ int mi355_unet_get_stats(const mi355_unet* net, int batch, mi355_unet_stats* out
   return 0;
 }
 
+int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels, const float* t,
+                       float* out, int batch, void* workspace, int64_t workspace_bytes, void* stream, mi355_op_profile* recs,
+                       int cap) {
+  MI355_REQUIRE(net && recs && cap > 0, -1, "unet_profile: bad argument");
+  std::vector<mi355_op_profile> prof;
+  std::vector<hipEvent_t> ev;
+  net->prof = &prof; net->prof_events = &ev;
+  int rc = unet_forward(net, x, x_channels, cond, cond_channels, t, out, batch, workspace, workspace_bytes, S(stream));
+  net->prof = nullptr; net->prof_events = nullptr;
+  hipError_t e = hipStreamSynchronize(S(stream));
+  if (rc == 0 && e == hipSuccess) {
+    for (size_t i = 0; i + 1 < ev.size() && i < prof.size(); ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      prof[i].ms = ms;
+    }
+  }
+  for (auto h : ev) hipEventDestroy(h);
+  if (rc) return rc;
+  if (e != hipSuccess) { mi355_set_error(hipGetErrorString(e)); return -3; }
+  const int n = (int)prof.size();
+  for (int i = 0; i < n && i < cap; ++i) recs[i] = prof[i];
+  return n;
+}
+
 // ---- sampler loops --------------------------------------------------------------------------------
 
 struct Scratch { float* t; float* v; float* none; char* unet_ws; int64_t unet_bytes; };

@@ -9,10 +9,14 @@
 //
 // GEMM view: M = output pixels (BM per workgroup: a rectangle of one image, or several whole small
 // images), N = output channels (BN per workgroup), K = taps x input channels, walked as
-// (64-byte channel chunk) x (kernel row) x (kernel column).  Per chunk the haloed input patch is
-// staged ONCE into LDS ([patch pixel][64 B], rows padded to 96 B so the 16-lane ds_read_b128 groups
-// of every tap shift are bank-conflict free) and re-read by all 9 taps at shifted row addresses;
-// weights arrive pre-tiled / pre-swizzled from the host packer so staging them is a linear copy.
+// (64-byte channel chunk) x (kernel row) x (kernel column).
+//   * Per chunk the haloed input patch is staged ONCE into LDS ([patch pixel][64 B], rows padded to
+//     96 B so the 16-lane ds_read_b128 groups of every tap shift are bank-conflict free) and re-read by
+//     all 9 taps at shifted row addresses.  1x1 convs stage three chunks as three "taps".
+//   * Weights arrive pre-tiled / pre-swizzled from the host packer, so staging is a linear copy.
+//   * Software pipeline (register staging, T14 style): the NEXT chunk's patch fragments and the NEXT
+//     kernel row's weight tiles are loaded into registers while the current row's MFMAs run; weight
+//     tiles are double-buffered in LDS, so there is one barrier per kernel row (48 MFMAs per wave).
 // 4 waves per workgroup, v_mfma_f32_16x16x32_bf16 (or v_mfma_f32_16x16x4_f32 in the fp32 build).
 #include "ops.h"
 
@@ -25,23 +29,22 @@ struct ConvKArgs {
   const void* src0; const void* src1;
   int C0, C1, Cin, nchunks;
   int N, Hs, Ws, Hc, Wc, Ho, Wo;
-  int mode, ks, pad, stride;
+  int mode, pad, stride;
   const float* pro_a; const float* pro_b; int pro_silu;
-  const void* w; const float* bias; int Cout;
+  const void* w; const float* bias; int Cout; int bn_pack;
   const float* emb; int emb_stride;
   const void* res; int res_mode; int Hr, Wr;
   void* out; int out_mode;
   int lvw, lth, G, PW, PH, NP, tiles_x, tiles_y;
-  int patch_bytes;
+  int plane_bytes;
 };
 
 template <typename T, bool FAST>
-__device__ __forceinline__ void load_transform(float (&f)[Elem<T>::VEC], const T* ptr, const float* a, const float* b,
-                                               int silu) {
+__device__ __forceinline__ void transform_frag(float (&f)[Elem<T>::VEC], const u32x4& raw, bool affine,
+                                               const float (&a)[Elem<T>::VEC], const float (&b)[Elem<T>::VEC], int silu) {
   constexpr int V = Elem<T>::VEC;
-  u32x4 raw = *reinterpret_cast<const u32x4*>(ptr);
   frag_to_float(raw, f, T());
-  if (a) {
+  if (affine) {
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float v = a[j] * f[j] + b[j];
@@ -50,18 +53,23 @@ __device__ __forceinline__ void load_transform(float (&f)[Elem<T>::VEC], const T
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(ConvKArgs p) {
+template <int I> struct IC { static constexpr int value = I; };
+
+// KS: 3 (3x3) or 1 (1x1: three channel chunks play the role of the three taps of a kernel row)
+// PIT: 16-B patch fragments per thread per plane (compile-time bound of the staging loops)
+template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK;
   constexpr bool FAST = (E::DTYPE == 1);
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
-  constexpr int WTILE = BN * 64;  // bytes of one (chunk, tap) weight tile
+  constexpr int WTILE = BN * 64;             // bytes of one (chunk, tap) weight tile of this workgroup
+  constexpr int WIT = (3 * WTILE + NTHREADS * 16 - 1) / (NTHREADS * 16);  // 16-B weight fragments per thread per kernel row
+  constexpr int NPL = KS == 1 ? 3 : 1;       // patch planes
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* patch = smem;
-  char* wlds = smem + p.patch_bytes;
-  int* srctab = reinterpret_cast<int*>(wlds + 3 * WTILE);
+  char* wlds = smem + NPL * p.plane_bytes;   // two buffers of 3*WTILE
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -75,20 +83,26 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(ConvKArgs p) {
   const int VWm = (1 << p.lvw) - 1, THm = (1 << p.lth) - 1;
   const int pimg = p.PH * p.PW;
 
-  // ---- patch pixel -> source pixel table (once per workgroup) ----
+  // ---- per-thread patch fragments: fragment u of this thread is patch pixel (tid>>2) + 64u, 16-B slot tid&3 ----
+  const int fq = tid & 3;
+  int sidx[PIT];   // source pixel index, -1 = zero padding / out of range
   {
     const int cy0 = y0 * p.stride - p.pad, cx0 = x0 * p.stride - p.pad;
-    for (int i = tid; i < p.NP; i += NTHREADS) {
-      const int g = i / pimg, r = i - g * pimg;
-      const int py = r / p.PW, px = r - py * p.PW;
-      const int n = n0 + g, cy = cy0 + py, cx = cx0 + px;
+#pragma unroll
+    for (int u = 0; u < PIT; ++u) {
+      const int i = (tid >> 2) + u * 64;
       int s = -1;
-      if (n < p.N && cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
-        if (p.mode == CONV_UP2) s = (n * p.Hs + (cy >> 1)) * p.Ws + (cx >> 1);
-        else if (p.mode == CONV_POOL2) s = (n * p.Hs + 2 * cy) * p.Ws + 2 * cx;
-        else s = (n * p.Hs + cy) * p.Ws + cx;
+      if (i < p.NP) {
+        const int g = i / pimg, r = i - g * pimg;
+        const int py = r / p.PW, px = r - py * p.PW;
+        const int n = n0 + g, cy = cy0 + py, cx = cx0 + px;
+        if (n < p.N && cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
+          if (p.mode == CONV_UP2) s = (n * p.Hs + (cy >> 1)) * p.Ws + (cx >> 1);
+          else if (p.mode == CONV_POOL2) s = (n * p.Hs + 2 * cy) * p.Ws + 2 * cx;
+          else s = (n * p.Hs + cy) * p.Ws + cx;
+        }
       }
-      srctab[i] = s;
+      sidx[u] = s;
     }
   }
 
@@ -111,73 +125,166 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  __syncthreads();
+  // packed weights: [nt_pack][chunk][tap][bn_pack rows][64 B]; this workgroup owns rows sub*BN .. of nt_pack
+  const int per = p.bn_pack / BN;
+  const int wtile_pack = p.bn_pack * 64;
+  const char* wbase = reinterpret_cast<const char*>(p.w) + (size_t)(nt / per) * p.nchunks * (KS * KS) * wtile_pack +
+                      (size_t)(nt % per) * WTILE;
+  const bool single = p.G == 1;   // whole tile inside one image: the prologue's (a, b) are per-thread constants per chunk
+  const bool prefetchable = p.mode != CONV_POOL2;
 
-  const int ks = p.ks, ntaps = ks * ks;
-  const char* wbase = reinterpret_cast<const char*>(p.w) + (size_t)nt * p.nchunks * ntaps * WTILE;
-  const int nfrag = p.NP * 4;
+  u32x4 raw[NPL][PIT];
+  u32x4 wreg[WIT];
+  float pa[NPL][V], pb[NPL][V];
 
-  for (int c = 0; c < p.nchunks; ++c) {
-    // ---------------- stage the input patch of this channel chunk (prologue fused) ----------------
-    {
-      const int cb = c * CHUNK;
-      const bool from0 = cb < p.C0;
-      const T* sp = from0 ? reinterpret_cast<const T*>(p.src0) + cb : reinterpret_cast<const T*>(p.src1) + (cb - p.C0);
-      const int Cs = from0 ? p.C0 : p.C1;
-      for (int e = tid; e < nfrag; e += NTHREADS) {
-        const int pix = e >> 2, q = e & 3;
-        const int s = srctab[pix];
+  auto chunk_src = [&](int c, const T*& sp, int& Cs) {
+    const int cb = c * CHUNK;
+    const bool from0 = cb < p.C0;
+    sp = from0 ? reinterpret_cast<const T*>(p.src0) + cb : reinterpret_cast<const T*>(p.src1) + (cb - p.C0);
+    Cs = from0 ? p.C0 : p.C1;
+  };
+  // issue the global loads of chunk c into plane register set PL (no waits).  PL is a compile-time constant and
+  // no pointer to a register array is ever formed: either would push the arrays into scratch memory.
+  auto prefetch_patch = [&](int c, auto plc) {
+    constexpr int pl = decltype(plc)::value;
+    if (prefetchable) {
+      const T* sp; int Cs;
+      chunk_src(c, sp, Cs);
+#pragma unroll
+      for (int u = 0; u < PIT; ++u) {
+        raw[pl][u] = u32x4{0u, 0u, 0u, 0u};
+        if (sidx[u] >= 0) raw[pl][u] = *reinterpret_cast<const u32x4*>(sp + (size_t)sidx[u] * Cs + fq * V);
+      }
+    }
+    if (p.pro_a && single) {
+      const float* ap = p.pro_a + (size_t)n0 * p.Cin + c * CHUNK + fq * V;
+      const float* bp = p.pro_b + (size_t)n0 * p.Cin + c * CHUNK + fq * V;
+#pragma unroll
+      for (int j = 0; j < V; ++j) { pa[pl][j] = ap[j]; pb[pl][j] = bp[j]; }
+    }
+  };
+  // transform + write chunk c (register set PL) into LDS plane PL
+  auto commit_patch = [&](int c, auto plc) {
+    constexpr int pl = decltype(plc)::value;
+    char* pl_base = patch + pl * p.plane_bytes;
+    const T* sp; int Cs;
+    chunk_src(c, sp, Cs);
+    const bool affine = p.pro_a != nullptr;
+#pragma unroll
+    for (int u = 0; u < PIT; ++u) {
+      const int pix = (tid >> 2) + u * 64;
+      if (pix < p.NP) {
         u32x4 outv = u32x4{0u, 0u, 0u, 0u};
-        if (s >= 0) {
-          const T* ptr = sp + (size_t)s * Cs + q * V;
-          if (p.pro_a == nullptr && p.mode != CONV_POOL2) {
-            outv = *reinterpret_cast<const u32x4*>(ptr);
+        if (sidx[u] >= 0) {
+          if (!affine && prefetchable) {
+            outv = raw[pl][u];
           } else {
-            const float* pa = nullptr; const float* pb = nullptr;
-            if (p.pro_a) {
-              const int n = n0 + (p.G > 1 ? pix / pimg : 0);
-              pa = p.pro_a + (size_t)n * p.Cin + cb + q * V;
-              pb = p.pro_b + (size_t)n * p.Cin + cb + q * V;
+            float av[V], bv[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) { av[j] = pa[pl][j]; bv[j] = pb[pl][j]; }
+            if (affine && !single) {
+              const int n = n0 + pix / pimg;
+              const float* ga = p.pro_a + (size_t)n * p.Cin + c * CHUNK + fq * V;
+              const float* gb = p.pro_b + (size_t)n * p.Cin + c * CHUNK + fq * V;
+#pragma unroll
+              for (int j = 0; j < V; ++j) { av[j] = ga[j]; bv[j] = gb[j]; }
             }
             float f[V];
-            if (p.mode == CONV_POOL2) {
+            if (prefetchable) {
+              transform_frag<T, FAST>(f, raw[pl][u], affine, av, bv, p.pro_silu);
+            } else {  // 2x2 average pool of the transformed source (ResBlock down=True)
+              const T* ptr = sp + (size_t)sidx[u] * Cs + fq * V;
               float t0[V], t1[V], t2[V], t3[V];
-              load_transform<T, FAST>(t0, ptr, pa, pb, p.pro_silu);
-              load_transform<T, FAST>(t1, ptr + Cs, pa, pb, p.pro_silu);
-              load_transform<T, FAST>(t2, ptr + (size_t)p.Ws * Cs, pa, pb, p.pro_silu);
-              load_transform<T, FAST>(t3, ptr + (size_t)(p.Ws + 1) * Cs, pa, pb, p.pro_silu);
+              transform_frag<T, FAST>(t0, *reinterpret_cast<const u32x4*>(ptr), affine, av, bv, p.pro_silu);
+              transform_frag<T, FAST>(t1, *reinterpret_cast<const u32x4*>(ptr + Cs), affine, av, bv, p.pro_silu);
+              transform_frag<T, FAST>(t2, *reinterpret_cast<const u32x4*>(ptr + (size_t)p.Ws * Cs), affine, av, bv, p.pro_silu);
+              transform_frag<T, FAST>(t3, *reinterpret_cast<const u32x4*>(ptr + (size_t)(p.Ws + 1) * Cs), affine, av, bv, p.pro_silu);
 #pragma unroll
               for (int j = 0; j < V; ++j) f[j] = 0.25f * ((t0[j] + t1[j]) + (t2[j] + t3[j]));
-            } else {
-              load_transform<T, FAST>(f, ptr, pa, pb, p.pro_silu);
             }
             outv = float_to_frag(f, T());
           }
         }
-        *reinterpret_cast<u32x4*>(patch + pix * PROW + q * 16) = outv;
+        *reinterpret_cast<u32x4*>(pl_base + pix * PROW + fq * 16) = outv;
       }
     }
-    // ---------------- kernel rows: stage ks weight tiles, MFMA over ks taps ----------------
-    for (int ky = 0; ky < ks; ++ky) {
-      const char* wsrc = wbase + ((size_t)c * ntaps + ky * ks) * WTILE;
-      for (int i = tid * 16; i < ks * WTILE; i += NTHREADS * 16)
-        *reinterpret_cast<u32x4*>(wlds + i) = *reinterpret_cast<const u32x4*>(wsrc + i);
-      __syncthreads();
-      for (int kx = 0; kx < ks; ++kx) {
-        const int tapoff = (ky * p.PW + kx) * PROW;
-        u32x4 a[MI], b[NI];
+  };
+  // weight tiles of one kernel row: `ntile` consecutive (chunk, tap) tiles starting at linear tile index t0
+  auto prefetch_w = [&](int t0, int ntile) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(patch + arow[mi] + tapoff);
+    for (int i = 0; i < WIT; ++i) {
+      const int off = (i * NTHREADS + tid) * 16;
+      const int tile = off / WTILE, inner = off - tile * WTILE;
+      wreg[i] = u32x4{0u, 0u, 0u, 0u};
+      if (tile < ntile) wreg[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(t0 + tile) * wtile_pack + inner);
+    }
+  };
+  auto commit_w = [&](int buf) {
+    char* dst = wlds + buf * (3 * WTILE);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(wlds + kx * WTILE + brow[ni]);
+    for (int i = 0; i < WIT; ++i) {
+      const int off = (i * NTHREADS + tid) * 16;
+      if (off < 3 * WTILE) *reinterpret_cast<u32x4*>(dst + off) = wreg[i];
+    }
+  };
+  auto mma_tap = [&](const char* pbase, int tapoff, const char* wt) {
+    u32x4 a[MI], b[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(pbase + arow[mi] + tapoff);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], a[mi], b[ni], T());
+    for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(wt + brow[ni]);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], a[mi], b[ni], T());
+  };
+
+  int gi = 0;  // kernel-row counter (weight buffer parity)
+  if constexpr (KS == 3) {
+    prefetch_patch(0, IC<0>());
+    prefetch_w(0, 3);
+    for (int c = 0; c < p.nchunks; ++c) {
+      if (c > 0) __syncthreads();           // every wave has finished reading the previous chunk's patch
+      commit_patch(c, IC<0>());
+      if (c + 1 < p.nchunks) prefetch_patch(c + 1, IC<0>());
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky, ++gi) {
+        commit_w(gi & 1);
+        __syncthreads();                    // patch + this row's weights visible; also orders buffer reuse (see header)
+        const int nxt = c * 9 + (ky + 1) * 3;
+        if (nxt < p.nchunks * 9) prefetch_w(nxt, 3);
+        const char* wt = wlds + (gi & 1) * (3 * WTILE);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) mma_tap(patch, (ky * p.PW + kx) * PROW, wt + kx * WTILE);
       }
+    }
+  } else {
+    const int ngroups = (p.nchunks + 2) / 3;
+    auto group_n = [&](int g) { return min(3, p.nchunks - 3 * g); };
+    auto prefetch_group = [&](int g) {
+      const int nn = group_n(g);
+      prefetch_patch(3 * g, IC<0>());
+      if (nn > 1) prefetch_patch(3 * g + 1, IC<1>());
+      if (nn > 2) prefetch_patch(3 * g + 2, IC<2>());
+      prefetch_w(3 * g, nn);
+    };
+    prefetch_group(0);
+    for (int g = 0; g < ngroups; ++g, ++gi) {
+      const int nc = group_n(g);
+      if (g > 0) __syncthreads();
+      commit_patch(3 * g, IC<0>());
+      if (nc > 1) commit_patch(3 * g + 1, IC<1>());
+      if (nc > 2) commit_patch(3 * g + 2, IC<2>());
+      commit_w(gi & 1);
       __syncthreads();
+      if (g + 1 < ngroups) prefetch_group(g + 1);
+      const char* wt = wlds + (gi & 1) * (3 * WTILE);
+      mma_tap(patch, 0, wt);
+      if (nc > 1) mma_tap(patch + p.plane_bytes, 0, wt + WTILE);
+      if (nc > 2) mma_tap(patch + 2 * p.plane_bytes, 0, wt + 2 * WTILE);
     }
   }
+  __syncthreads();   // LDS is re-used by the epilogue
 
   // ---------------- epilogue: acc -> LDS (wave-private fp32 tile) -> coalesced rows ----------------
   constexpr int RP = WTM >= 32 ? 32 : 16;   // rows per pass
@@ -200,6 +307,8 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(ConvKArgs p) {
       constexpr int RPI = 64 / LPR;         // rows per wave iteration
       const int c4 = (lane % LPR) * 4, r_in = lane / LPR;
       const int co = co_w + c4;
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias && co < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
       for (int it = 0; it < RP / RPI; ++it) {
         const int r = it * RPI + r_in;
@@ -208,12 +317,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(ConvKArgs p) {
         const int n = n0 + g, y = y0 + ty, x = x0 + tx;
         if (n < p.N && y < p.Ho && x < p.Wo && co < p.Cout) {
           f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * SST + c4);
-          float o[4] = {v[0], v[1], v[2], v[3]};
-          if (p.bias) {
-            f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += bv[j];
-          }
+          float o[4] = {v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
           if (p.emb) {
             f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)n * p.emb_stride + co);
 #pragma unroll
@@ -275,27 +379,47 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(ConvKArgs p) {
   }
 }
 
-struct TileCfg { int BM, BN; };
-
-template <typename T, int BM, int BN, int WM, int WN>
-void launch_t(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), grid, dim3(NTHREADS), lds, s, a);
-}
-
-template <typename T>
-int launch_cfg(const ConvKArgs& a, int BM, int BN, dim3 grid, size_t lds, hipStream_t s) {
-  if (BM == 128 && BN == 128) launch_t<T, 128, 128, 2, 2>(a, grid, lds, s);
-  else if (BM == 128 && BN == 64) launch_t<T, 128, 64, 2, 2>(a, grid, lds, s);
-  else if (BM == 128 && BN == 32) launch_t<T, 128, 32, 4, 1>(a, grid, lds, s);
-  else if (BM == 64 && BN == 128) launch_t<T, 64, 128, 2, 2>(a, grid, lds, s);
-  else if (BM == 64 && BN == 64) launch_t<T, 64, 64, 2, 2>(a, grid, lds, s);
-  else if (BM == 64 && BN == 32) launch_t<T, 64, 32, 4, 1>(a, grid, lds, s);
-  else { mi355_set_error("conv: unsupported tile"); return -4; }
+template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT>
+int launch_t(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, KS, PIT>;
+  static bool attr_done = false;  // allow > 64 KB of dynamic LDS (the CU has 160 KB)
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { (void)hipGetLastError(); }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, a);
   return 0;
 }
 
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_ks(const ConvKArgs& a, int ks, int pit, dim3 grid, size_t lds, hipStream_t s) {
+  if (ks == 1) {
+    if (pit <= 2) return launch_t<T, BM, BN, WM, WN, 1, 2>(a, grid, lds, s);
+    mi355_set_error("conv: 1x1 patch too large");
+    return -4;
+  }
+  if (pit <= 4) return launch_t<T, BM, BN, WM, WN, 3, 4>(a, grid, lds, s);
+  if (pit <= 7) return launch_t<T, BM, BN, WM, WN, 3, 7>(a, grid, lds, s);
+  if (pit <= 11) return launch_t<T, BM, BN, WM, WN, 3, 11>(a, grid, lds, s);
+  mi355_set_error("conv: patch too large");
+  return -4;
+}
+
+template <typename T>
+int launch_cfg(const ConvKArgs& a, int BM, int BN, int ks, int pit, dim3 grid, size_t lds, hipStream_t s) {
+  if (BM == 128 && BN == 128) return launch_ks<T, 128, 128, 2, 2>(a, ks, pit, grid, lds, s);
+  if (BM == 128 && BN == 64) return launch_ks<T, 128, 64, 2, 2>(a, ks, pit, grid, lds, s);
+  if (BM == 128 && BN == 32) return launch_ks<T, 128, 32, 4, 1>(a, ks, pit, grid, lds, s);
+  if (BM == 64 && BN == 128) return launch_ks<T, 64, 128, 2, 2>(a, ks, pit, grid, lds, s);
+  if (BM == 64 && BN == 64) return launch_ks<T, 64, 64, 2, 2>(a, ks, pit, grid, lds, s);
+  if (BM == 64 && BN == 32) return launch_ks<T, 64, 32, 4, 1>(a, ks, pit, grid, lds, s);
+  mi355_set_error("conv: unsupported tile");
+  return -4;
+}
+
 struct Geo {
-  int Hc, Wc, Ho, Wo, BM, BN, lvw, lth, G, PW, PH, NP, tiles_x, tiles_y, groups, pad, stride, patch_bytes;
+  int Hc, Wc, Ho, Wo, BM, BN, bn_pack, lvw, lth, G, PW, PH, NP, tiles_x, tiles_y, groups, pad, stride, plane_bytes, pit;
   size_t lds;
 };
 
@@ -307,10 +431,20 @@ int compute_geo(const ConvDesc& d, Geo& g) {
   else { g.Hc = d.Hs; g.Wc = d.Ws; }
   if (d.mode == CONV_STRIDE2) { g.Ho = (g.Hc + 2 * g.pad - d.ks) / 2 + 1; g.Wo = (g.Wc + 2 * g.pad - d.ks) / 2 + 1; }
   else { g.Ho = g.Hc; g.Wo = g.Wc; }
-  g.BN = conv_tile_n(d.Cout);
+  g.bn_pack = conv_tile_n(d.Cout);
+  // Tile choice: the largest tile that still gives every CU two workgroups; otherwise the smallest tile.
   const long M = (long)d.N * g.Ho * g.Wo;
-  const long tiles128 = ((M + 127) / 128) * ((d.Cout + g.BN - 1) / g.BN);
-  g.BM = tiles128 >= 512 ? 128 : 64;
+  const int P = g.bn_pack, Q = P > 64 ? 64 : P;
+  int cand[4][2]; int nc = 0;
+  cand[nc][0] = 128; cand[nc++][1] = P;
+  cand[nc][0] = 64; cand[nc++][1] = P;
+  if (Q != P) { cand[nc][0] = 64; cand[nc++][1] = Q; }
+  int bestBM = cand[nc - 1][0], bestBN = cand[nc - 1][1];
+  for (int i = 0; i < nc; ++i) {
+    const long wgs = ((M + cand[i][0] - 1) / cand[i][0]) * ((d.Cout + cand[i][1] - 1) / cand[i][1]);
+    if (wgs >= 512) { bestBM = cand[i][0]; bestBN = cand[i][1]; break; }
+  }
+  g.BM = bestBM; g.BN = bestBN;
   const int lw = ilog2_ceil(g.Wo);
   g.lvw = (1 << lw) > g.BM ? ilog2_ceil(g.BM) : lw;
   const int VW = 1 << g.lvw;
@@ -324,8 +458,10 @@ int compute_geo(const ConvDesc& d, Geo& g) {
   if (g.stride == 2) { g.PW = 2 * VW + 1; g.PH = 2 * THp + 1; }
   else { g.PW = VW + 2 * g.pad; g.PH = THp + 2 * g.pad; }
   g.NP = g.G * g.PH * g.PW;
-  g.patch_bytes = ((g.NP * PROW + 15) / 16) * 16;
-  size_t main_lds = (size_t)g.patch_bytes + 3 * (size_t)g.BN * 64 + (size_t)g.NP * 4;
+  g.plane_bytes = ((g.NP * PROW + 15) / 16) * 16;
+  g.pit = (g.NP + 63) / 64;
+  const int npl = d.ks == 1 ? 3 : 1;
+  size_t main_lds = (size_t)npl * g.plane_bytes + 2 * 3 * (size_t)g.BN * 64;
   const int WN = g.BN == 32 ? 1 : 2, WM = 4 / WN;
   const int WTM = g.BM / WM, WTN = g.BN / WN;
   const int RP = WTM >= 32 ? 32 : 16;
@@ -403,19 +539,19 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   ConvKArgs a;
   a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = Cin / CH;
   a.N = d.N; a.Hs = d.Hs; a.Ws = d.Ws; a.Hc = g.Hc; a.Wc = g.Wc; a.Ho = g.Ho; a.Wo = g.Wo;
-  a.mode = d.mode; a.ks = d.ks; a.pad = g.pad; a.stride = g.stride;
+  a.mode = d.mode; a.pad = g.pad; a.stride = g.stride;
   a.pro_a = d.pro_a; a.pro_b = d.pro_b; a.pro_silu = d.pro_silu;
-  a.w = d.w; a.bias = d.bias; a.Cout = d.Cout;
+  a.w = d.w; a.bias = d.bias; a.Cout = d.Cout; a.bn_pack = g.bn_pack;
   a.emb = d.emb; a.emb_stride = d.emb_stride;
   a.res = d.res; a.res_mode = d.res ? d.res_mode : RES_NONE;
   a.Hr = d.res_mode == RES_UP2 ? g.Ho / 2 : (d.res_mode == RES_POOL2 ? g.Ho * 2 : g.Ho);
   a.Wr = d.res_mode == RES_UP2 ? g.Wo / 2 : (d.res_mode == RES_POOL2 ? g.Wo * 2 : g.Wo);
   a.out = d.out; a.out_mode = d.out_mode;
   a.lvw = g.lvw; a.lth = g.lth; a.G = g.G; a.PW = g.PW; a.PH = g.PH; a.NP = g.NP;
-  a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.patch_bytes = g.patch_bytes;
+  a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.plane_bytes = g.plane_bytes;
   dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
-  int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, grid, g.lds, stream)
-                        : launch_cfg<bf16>(a, g.BM, g.BN, grid, g.lds, stream);
+  int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, d.ks, g.pit, grid, g.lds, stream)
+                        : launch_cfg<bf16>(a, g.BM, g.BN, d.ks, g.pit, grid, g.lds, stream);
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   return 0;

@@ -24,26 +24,39 @@ __global__ void timestep_embedding_kernel(const float* t, int B, int dim, float 
   out[idx] = v;
 }
 
-// out[b][j] = bias[j] + sum_k act(in[b][k]) * Wt[k][j].  One thread per (j, 8-row batch slab):
-// Wt reads are coalesced across lanes, in[b][k] is wave-uniform (scalar loads).
+// out[b][j] = bias[j] + sum_k act(in[b][k]) * Wt[k][j].  One thread per (j, 8-row batch slab): the 8 input rows
+// are staged in LDS (broadcast reads), Wt reads are coalesced across lanes, 4 independent loads in flight.
 constexpr int LB = 8;
-__global__ void __launch_bounds__(128) linear_kernel(const float* in, const float* Wt, const float* bias, float* out, int B,
-                                                     int K, int J, int in_act, int out_act) {
+__global__ void __launch_bounds__(128) linear_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int B, int K, int J,
+                                                     int in_act, int out_act) {
+  extern __shared__ float xin[];  // [LB][K]
   const int j = blockIdx.x * 128 + threadIdx.x;
   const int b0 = blockIdx.y * LB;
+  for (int i = threadIdx.x; i < LB * K; i += 128) {
+    const int r = i / K, k = i - r * K;
+    float x = b0 + r < B ? in[(size_t)(b0 + r) * K + k] : 0.f;
+    xin[i] = in_act ? silu_f<false>(x) : x;
+  }
+  __syncthreads();
   if (j >= J) return;
   float acc[LB];
 #pragma unroll
   for (int r = 0; r < LB; ++r) acc[r] = 0.f;
-  for (int k = 0; k < K; ++k) {
-    const float w = Wt[(size_t)k * J + j];
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {
+    const float w0 = Wt[(size_t)k * J + j], w1 = Wt[(size_t)(k + 1) * J + j];
+    const float w2 = Wt[(size_t)(k + 2) * J + j], w3 = Wt[(size_t)(k + 3) * J + j];
 #pragma unroll
     for (int r = 0; r < LB; ++r) {
-      const int b = b0 + r;
-      float x = b < B ? in[(size_t)b * K + k] : 0.f;
-      if (in_act) x = silu_f<false>(x);
-      acc[r] = fmaf(x, w, acc[r]);
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xin + r * K + k);
+      acc[r] = fmaf(x[3], w3, fmaf(x[2], w2, fmaf(x[1], w1, fmaf(x[0], w0, acc[r]))));
     }
+  }
+  for (; k < K; ++k) {
+    const float w = Wt[(size_t)k * J + j];
+#pragma unroll
+    for (int r = 0; r < LB; ++r) acc[r] = fmaf(xin[r * K + k], w, acc[r]);
   }
   const float bj = bias ? bias[j] : 0.f;
 #pragma unroll
@@ -117,7 +130,8 @@ int timestep_embedding_launch(const float* t, int B, int dim, float max_period, 
 int linear_launch(const float* in, const float* Wt, const float* bias, float* out, int B, int K, int J, int in_act, int out_act,
                   hipStream_t s) {
   dim3 grid((J + 127) / 128, (B + LB - 1) / LB);
-  hipLaunchKernelGGL(linear_kernel, grid, dim3(128), 0, s, in, Wt, bias, out, B, K, J, in_act, out_act);
+  MI355_REQUIRE(K % 4 == 0 && (size_t)LB * K * 4 <= 64 * 1024, -4, "linear: K must be a multiple of 4 and <= 2048");
+  hipLaunchKernelGGL(linear_kernel, grid, dim3(128), (size_t)LB * K * 4, s, in, Wt, bias, out, B, K, J, in_act, out_act);
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -49,6 +49,9 @@ struct mi355_unet {
   // stats per image
   double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;
   int64_t launches = 0;
+  // optional per-op profiling (mi355_unet_profile)
+  std::vector<mi355_op_profile>* prof = nullptr;
+  std::vector<hipEvent_t>* prof_events = nullptr;
 };
 
 int unet_build(const mi355_unet_config& cfg, const float* const* params_host, int n_params, void* dev_weights,

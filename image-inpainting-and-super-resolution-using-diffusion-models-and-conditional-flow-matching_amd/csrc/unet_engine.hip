@@ -400,6 +400,12 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
   auto TP = [&](int id) -> void* { return id < 0 ? nullptr : ws + l.arena + net->tensors[id].offset_per_image * (size_t)B * esz; };
   int rc;
   net->launches = 0;
+  auto mark = [&](const mi355_op_profile& r) {
+    if (!net->prof) return;
+    hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, stream);
+    net->prof_events->push_back(e); net->prof->push_back(r);
+  };
+  if (net->prof) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, stream); net->prof_events->push_back(e); }
   // time embedding path (fp32): emb2 = silu(time_embed(timestep_embedding(t))) ; embp = all emb_layers linears
   if ((rc = timestep_embedding_launch(t, B, mc, 10000.f, F(l.temb), stream))) return rc;
   if ((rc = linear_launch(F(l.temb), WF(net->te_w0), WF(net->te_b0), F(l.emb1), B, mc, 4 * mc, 0, 1, stream))) return rc;
@@ -408,7 +414,9 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
   const int S = net->cfg.image_size;
   if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
   net->launches += 5;
+  { mi355_op_profile r{}; r.kind = MI355_OP_PRELUDE; mark(r); }
   for (const PlanOp& op : net->ops) {
+    mi355_op_profile r{};
     const PlanTensor& s0 = net->tensors[op.src0];
     const int C1 = op.src1 >= 0 ? net->tensors[op.src1].C : 0;
     if (op.kind == OP_GN) {
@@ -417,6 +425,8 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
       if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = net->emb_total; }
       g.a = F(l.gna); g.b = F(l.gnb);
       rc = gn_affine_launch(g, stream);
+      r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
+      r.bytes = (double)B * s0.H * s0.W * (s0.C + C1) * esz;
     } else if (op.kind == OP_CONV) {
       ConvDesc c; c.dtype = dtype; c.src0 = TP(op.src0); c.C0 = s0.C; c.src1 = TP(op.src1); c.C1 = C1;
       c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks;
@@ -427,14 +437,26 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
       c.out_mode = op.out_mode;
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
       rc = conv_launch(c, stream);
+      if (net->prof) {
+        const ConvGeom cg = conv_geometry(c);
+        const int cin = s0.C + C1;
+        r.kind = MI355_OP_CONV; r.ks = op.ks; r.cin = cin; r.cout = op.Cout; r.h = cg.Ho; r.w = cg.Wo; r.tile_m = cg.BM; r.tile_n = cg.BN;
+        r.flops = 2.0 * B * cg.Ho * cg.Wo * (double)op.Cout * cin * op.ks * op.ks;
+        r.bytes = ((double)B * s0.H * s0.W * cin + (double)B * cg.Ho * cg.Wo * op.Cout) * esz + (double)op.Cout * cin * op.ks * op.ks * esz;
+      }
     } else if (op.kind == OP_ATTN) {
       AttnDesc a; a.dtype = dtype; a.qkv = TP(op.src0); a.out = TP(op.dst); a.N = B; a.T = s0.H * s0.W;
       a.heads = op.heads; a.ch = op.ch; a.new_order = net->cfg.use_new_attention_order;
       rc = attention_launch(a, stream);
+      r.kind = MI355_OP_ATTN; r.cin = 3 * op.heads * op.ch; r.cout = op.heads * op.ch; r.h = s0.H; r.w = s0.W;
+      r.flops = 4.0 * B * (double)a.T * a.T * op.heads * op.ch;
+      r.bytes = 4.0 * B * a.T * op.heads * op.ch * esz;
     } else {
       rc = resample_launch(dtype, TP(op.src0), TP(op.dst), B, s0.H, s0.W, s0.C, op.mode, stream);
+      r.kind = MI355_OP_RESAMPLE; r.cin = s0.C; r.h = s0.H; r.w = s0.W;
     }
     if (rc) return rc;
+    mark(r);
     ++net->launches;
   }
   return 0;

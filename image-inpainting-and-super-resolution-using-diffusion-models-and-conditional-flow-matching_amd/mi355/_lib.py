@@ -38,6 +38,12 @@ class UNetStatsC(C.Structure):
                 ("act_bytes", C.c_double), ("weight_bytes", C.c_double)]
 
 
+class OpProfileC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ks", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("h", C.c_int32),
+                ("w", C.c_int32), ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 _FP = C.POINTER(C.c_float)
 
 
@@ -68,6 +74,7 @@ SIGNATURES = {
     "mi355_unet_workspace_bytes": (_I64, [_VP, _I]),
     "mi355_unet_forward": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
     "mi355_unet_get_stats": (_I, [_VP, _I, C.POINTER(UNetStatsC)]),
+    "mi355_unet_profile": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _I64, _VP, C.POINTER(OpProfileC), _I]),
     "mi355_cfm_euler_sample": (_I, [_VP, _VP, _I, _VP, _I, _FP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
     "mi355_ddpm_sample": (_I, [_VP, _VP, _I, _VP, C.POINTER(DDPMTablesC), C.POINTER(DDPMOptionsC), _VP, _I64, _I, _VP, _I64, _VP]),
     "mi355_timestep_embedding": (_I, [_VP, _I, _I, _F, _VP, _VP]),

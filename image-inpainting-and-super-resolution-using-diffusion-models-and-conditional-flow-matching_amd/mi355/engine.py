@@ -111,6 +111,20 @@ class UNetEngine:
               "mi355_unet_forward")
         return out
 
+    def profile(self, x: torch.Tensor, t: torch.Tensor, cond: Optional[torch.Tensor] = None):
+        """One forward with HIP events around every op -> list of dicts (kind, ks, cin, cout, h, w, tile, ms, flops, bytes)."""
+        B, Cx, Cc = self._split(x, cond)
+        out = torch.empty(B, self.out_channels, self.image_size, self.image_size, device=self.device, dtype=torch.float32)
+        ws, wsb = self.workspace(B)
+        cap = 4096
+        recs = (_lib.OpProfileC * cap)()
+        n = check(self.L.mi355_unet_profile(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
+                                            Cc, self._chk(t, "timesteps"), self._chk(out, "out"), B, ws, wsb, self._stream(), recs, cap),
+                  "mi355_unet_profile")
+        names = {0: "prelude", 1: "gn_stats", 2: "conv", 3: "attention", 4: "resample"}
+        return [dict(kind=names[r.kind], ks=r.ks, cin=r.cin, cout=r.cout, h=r.h, w=r.w, tile=(r.tile_m, r.tile_n), ms=r.ms,
+                     flops=r.flops, bytes=r.bytes) for r in recs[:min(n, cap)]]
+
     def stats(self, batch: int):
         s = _lib.UNetStatsC()
         check(self.L.mi355_unet_get_stats(self.handle, batch, C.byref(s)))

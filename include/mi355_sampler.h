@@ -94,6 +94,25 @@ typedef struct mi355_unet_stats {
 } mi355_unet_stats;
 int mi355_unet_get_stats(const mi355_unet* net, int batch, mi355_unet_stats* out);
 
+/* One forward with a HIP event pair around every device op of the plan (synchronises the stream at the end).
+ * Fills up to `cap` records in launch order and returns the number of ops; used by bench.py to measure the
+ * dominant kernel's average launch duration live, beside its algorithmic FLOPs / bytes. */
+#define MI355_OP_PRELUDE 0 /* timestep embedding + time/emb linears + NCHW->NHWC pack (5 launches) */
+#define MI355_OP_GN 1
+#define MI355_OP_CONV 2
+#define MI355_OP_ATTN 3
+#define MI355_OP_RESAMPLE 4
+typedef struct mi355_op_profile {
+  int32_t kind, ks, cin, cout, h, w; /* conv: kernel size, in/out channels, OUTPUT height/width */
+  int32_t tile_m, tile_n;            /* conv: workgroup tile */
+  float ms;
+  double flops; /* algorithmic 2*MAC */
+  double bytes; /* algorithmic bytes: activations in + out (+ weights once) */
+} mi355_op_profile;
+int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels, const float* t,
+                       float* out, int batch, void* workspace, int64_t workspace_bytes, void* stream,
+                       mi355_op_profile* recs, int cap);
+
 /* ---- sampler loops ------------------------------------------------------------------------------ */
 
 /* Fixed-step Euler CFM sampler: x_{k+1} = x_k + (t_{k+1}-t_k) * model(t_k, x_k)
