@@ -36,40 +36,36 @@ struct ConvKArgs {
   const void* res; int res_mode; int Hr, Wr;
   void* out; int out_mode;
   int lvw, lth, G, PW, PH, NP, tiles_x, tiles_y;
-  int plane_bytes;
+  uint32_t bytes0, bytes1, wbytes;   // buffer sizes (raw buffer descriptors: out-of-range loads return 0)
 };
 
-template <typename T, bool FAST>
-__device__ __forceinline__ void transform_frag(float (&f)[Elem<T>::VEC], const u32x4& raw, bool affine,
-                                               const float (&a)[Elem<T>::VEC], const float (&b)[Elem<T>::VEC], int silu) {
-  constexpr int V = Elem<T>::VEC;
-  frag_to_float(raw, f, T());
-  if (affine) {
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      float v = a[j] * f[j] + b[j];
-      f[j] = silu ? silu_f<FAST>(v) : v;
-    }
-  }
+template <int I> struct IC { static constexpr int value = I; };
+
+template <bool FAST> __device__ __forceinline__ float silu_fast(float v) {
+  if (FAST) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+  return v / (1.0f + expf(-v));
 }
 
-template <int I> struct IC { static constexpr int value = I; };
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 
 // KS: 3 (3x3) or 1 (1x1: three channel chunks play the role of the three taps of a kernel row)
 // PIT: 16-B patch fragments per thread per plane (compile-time bound of the staging loops)
 template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
   using E = Elem<T>;
-  constexpr int V = E::VEC, CHUNK = E::CHUNK;
+  constexpr int V = E::VEC, CHUNK = E::CHUNK, ESZ = sizeof(T);
   constexpr bool FAST = (E::DTYPE == 1);
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   constexpr int WTILE = BN * 64;             // bytes of one (chunk, tap) weight tile of this workgroup
   constexpr int WIT = (3 * WTILE + NTHREADS * 16 - 1) / (NTHREADS * 16);  // 16-B weight fragments per thread per kernel row
   constexpr int NPL = KS == 1 ? 3 : 1;       // patch planes
+  constexpr int PLANE = PIT * 64 * PROW;     // bytes per plane (every thread owns PIT fragment slots: no bounds checks)
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* patch = smem;
-  char* wlds = smem + NPL * p.plane_bytes;   // two buffers of 3*WTILE
+  char* wlds = smem + NPL * PLANE;           // two buffers of 3*WTILE
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -83,14 +79,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
   const int VWm = (1 << p.lvw) - 1, THm = (1 << p.lth) - 1;
   const int pimg = p.PH * p.PW;
 
+  // wave-uniform buffer descriptors (kernel arguments only): 32-bit per-lane offsets, OOB -> 0, no 64-bit address math
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src1 ? p.src1 : p.src0), 0, p.bytes1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wbytes, 0x00020000);
+
   // ---- per-thread patch fragments: fragment u of this thread is patch pixel (tid>>2) + 64u, 16-B slot tid&3 ----
-  const int fq = tid & 3;
-  int sidx[PIT];   // source pixel index, -1 = zero padding / out of range
+  const int fq = tid & 3, frow = tid >> 2;
+  int sidx[PIT];        // source pixel index, -1 = zero padding / out of range
+  uint32_t voff[PIT];   // byte offset of the fragment in the CURRENT source tensor (>= size when invalid)
+  uint32_t vmask = 0;
   {
     const int cy0 = y0 * p.stride - p.pad, cx0 = x0 * p.stride - p.pad;
 #pragma unroll
     for (int u = 0; u < PIT; ++u) {
-      const int i = (tid >> 2) + u * 64;
+      const int i = frow + u * 64;
       int s = -1;
       if (i < p.NP) {
         const int g = i / pimg, r = i - g * pimg;
@@ -103,6 +106,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
         }
       }
       sidx[u] = s;
+      voff[u] = s >= 0 ? (uint32_t)s * (uint32_t)(p.C0 * ESZ) + fq * 16 : p.bytes0;
+      if (s >= 0) vmask |= 1u << u;
     }
   }
 
@@ -127,38 +132,46 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
 
   // packed weights: [nt_pack][chunk][tap][bn_pack rows][64 B]; this workgroup owns rows sub*BN .. of nt_pack
   const int per = p.bn_pack / BN;
-  const int wtile_pack = p.bn_pack * 64;
-  const char* wbase = reinterpret_cast<const char*>(p.w) + (size_t)(nt / per) * p.nchunks * (KS * KS) * wtile_pack +
-                      (size_t)(nt % per) * WTILE;
+  const uint32_t wtile_pack = p.bn_pack * 64;
+  const uint32_t wbase = (uint32_t)(nt / per) * p.nchunks * (KS * KS) * wtile_pack + (uint32_t)(nt % per) * WTILE;
+  uint32_t woff[WIT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const uint32_t off = (i * NTHREADS + tid) * 16;
+    const uint32_t tile = off / WTILE, inner = off - tile * WTILE;
+    woff[i] = off < 3 * WTILE ? tile * wtile_pack + inner : p.wbytes;
+  }
   const bool single = p.G == 1;   // whole tile inside one image: the prologue's (a, b) are per-thread constants per chunk
   const bool prefetchable = p.mode != CONV_POOL2;
+  const int pro = p.pro_a == nullptr ? 0 : (p.pro_silu ? 2 : 1);
 
   u32x4 raw[NPL][PIT];
   u32x4 wreg[WIT];
   float pa[NPL][V], pb[NPL][V];
 
-  auto chunk_src = [&](int c, const T*& sp, int& Cs) {
-    const int cb = c * CHUNK;
-    const bool from0 = cb < p.C0;
-    sp = from0 ? reinterpret_cast<const T*>(p.src0) + cb : reinterpret_cast<const T*>(p.src1) + (cb - p.C0);
-    Cs = from0 ? p.C0 : p.C1;
-  };
   // issue the global loads of chunk c into plane register set PL (no waits).  PL is a compile-time constant and
   // no pointer to a register array is ever formed: either would push the arrays into scratch memory.
   auto prefetch_patch = [&](int c, auto plc) {
     constexpr int pl = decltype(plc)::value;
+    const int cb = c * CHUNK;
     if (prefetchable) {
-      const T* sp; int Cs;
-      chunk_src(c, sp, Cs);
+      if (cb < p.C0) {
+        const uint32_t so = cb * ESZ;
 #pragma unroll
-      for (int u = 0; u < PIT; ++u) {
-        raw[pl][u] = u32x4{0u, 0u, 0u, 0u};
-        if (sidx[u] >= 0) raw[pl][u] = *reinterpret_cast<const u32x4*>(sp + (size_t)sidx[u] * Cs + fq * V);
+        for (int u = 0; u < PIT; ++u) raw[pl][u] = buf_load16(rs0, voff[u], so);
+      } else {
+        if (cb == p.C0) {  // first chunk of the second (skip-concat) source: re-base the fragment offsets once
+#pragma unroll
+          for (int u = 0; u < PIT; ++u) voff[u] = sidx[u] >= 0 ? (uint32_t)sidx[u] * (uint32_t)(p.C1 * ESZ) + fq * 16 : p.bytes1;
+        }
+        const uint32_t so = (cb - p.C0) * ESZ;
+#pragma unroll
+        for (int u = 0; u < PIT; ++u) raw[pl][u] = buf_load16(rs1, voff[u], so);
       }
     }
-    if (p.pro_a && single) {
-      const float* ap = p.pro_a + (size_t)n0 * p.Cin + c * CHUNK + fq * V;
-      const float* bp = p.pro_b + (size_t)n0 * p.Cin + c * CHUNK + fq * V;
+    if (pro && single) {
+      const float* ap = p.pro_a + (size_t)n0 * p.Cin + cb + fq * V;
+      const float* bp = p.pro_b + (size_t)n0 * p.Cin + cb + fq * V;
 #pragma unroll
       for (int j = 0; j < V; ++j) { pa[pl][j] = ap[j]; pb[pl][j] = bp[j]; }
     }
@@ -166,83 +179,92 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
   // transform + write chunk c (register set PL) into LDS plane PL
   auto commit_patch = [&](int c, auto plc) {
     constexpr int pl = decltype(plc)::value;
-    char* pl_base = patch + pl * p.plane_bytes;
-    const T* sp; int Cs;
-    chunk_src(c, sp, Cs);
-    const bool affine = p.pro_a != nullptr;
+    char* dst = patch + pl * PLANE + frow * PROW + fq * 16;
+    if (pro == 0 && prefetchable) {
+#pragma unroll
+      for (int u = 0; u < PIT; ++u) *reinterpret_cast<u32x4*>(dst + u * 64 * PROW) = raw[pl][u];
+      return;
+    }
+    const int cb = c * CHUNK;
 #pragma unroll
     for (int u = 0; u < PIT; ++u) {
-      const int pix = (tid >> 2) + u * 64;
-      if (pix < p.NP) {
-        u32x4 outv = u32x4{0u, 0u, 0u, 0u};
-        if (sidx[u] >= 0) {
-          if (!affine && prefetchable) {
-            outv = raw[pl][u];
-          } else {
-            float av[V], bv[V];
+      float av[V], bv[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) { av[j] = pa[pl][j]; bv[j] = pb[pl][j]; }
-            if (affine && !single) {
-              const int n = n0 + pix / pimg;
-              const float* ga = p.pro_a + (size_t)n * p.Cin + c * CHUNK + fq * V;
-              const float* gb = p.pro_b + (size_t)n * p.Cin + c * CHUNK + fq * V;
+      for (int j = 0; j < V; ++j) { av[j] = pa[pl][j]; bv[j] = pb[pl][j]; }
+      if (pro && !single && sidx[u] >= 0) {
+        const int n = n0 + (frow + u * 64) / pimg;
+        const float* ga = p.pro_a + (size_t)n * p.Cin + cb + fq * V;
+        const float* gb = p.pro_b + (size_t)n * p.Cin + cb + fq * V;
 #pragma unroll
-              for (int j = 0; j < V; ++j) { av[j] = ga[j]; bv[j] = gb[j]; }
-            }
-            float f[V];
-            if (prefetchable) {
-              transform_frag<T, FAST>(f, raw[pl][u], affine, av, bv, p.pro_silu);
-            } else {  // 2x2 average pool of the transformed source (ResBlock down=True)
-              const T* ptr = sp + (size_t)sidx[u] * Cs + fq * V;
-              float t0[V], t1[V], t2[V], t3[V];
-              transform_frag<T, FAST>(t0, *reinterpret_cast<const u32x4*>(ptr), affine, av, bv, p.pro_silu);
-              transform_frag<T, FAST>(t1, *reinterpret_cast<const u32x4*>(ptr + Cs), affine, av, bv, p.pro_silu);
-              transform_frag<T, FAST>(t2, *reinterpret_cast<const u32x4*>(ptr + (size_t)p.Ws * Cs), affine, av, bv, p.pro_silu);
-              transform_frag<T, FAST>(t3, *reinterpret_cast<const u32x4*>(ptr + (size_t)(p.Ws + 1) * Cs), affine, av, bv, p.pro_silu);
-#pragma unroll
-              for (int j = 0; j < V; ++j) f[j] = 0.25f * ((t0[j] + t1[j]) + (t2[j] + t3[j]));
-            }
-            outv = float_to_frag(f, T());
-          }
-        }
-        *reinterpret_cast<u32x4*>(pl_base + pix * PROW + fq * 16) = outv;
+        for (int j = 0; j < V; ++j) { av[j] = ga[j]; bv[j] = gb[j]; }
       }
+      float f[V];
+      auto xform = [&](const u32x4& rw, float (&o)[V]) {
+        frag_to_float(rw, o, T());
+        if (pro == 2) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = silu_fast<FAST>(av[j] * o[j] + bv[j]);
+        } else if (pro == 1) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = av[j] * o[j] + bv[j];
+        }
+      };
+      if (prefetchable) {
+        xform(raw[pl][u], f);
+      } else {  // 2x2 average pool of the transformed source (ResBlock down=True): rare, plain loads
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[j] = 0.f;
+        if (sidx[u] >= 0) {
+          const bool from0 = cb < p.C0;
+          const T* sp = from0 ? reinterpret_cast<const T*>(p.src0) + cb : reinterpret_cast<const T*>(p.src1) + (cb - p.C0);
+          const int Cs = from0 ? p.C0 : p.C1;
+          const T* ptr = sp + (size_t)sidx[u] * Cs + fq * V;
+          float t0[V], t1[V], t2[V], t3[V];
+          xform(*reinterpret_cast<const u32x4*>(ptr), t0);
+          xform(*reinterpret_cast<const u32x4*>(ptr + Cs), t1);
+          xform(*reinterpret_cast<const u32x4*>(ptr + (size_t)p.Ws * Cs), t2);
+          xform(*reinterpret_cast<const u32x4*>(ptr + (size_t)(p.Ws + 1) * Cs), t3);
+#pragma unroll
+          for (int j = 0; j < V; ++j) f[j] = 0.25f * ((t0[j] + t1[j]) + (t2[j] + t3[j]));
+        }
+      }
+      u32x4 outv = float_to_frag(f, T());
+      if (!((vmask >> u) & 1u)) outv = u32x4{0u, 0u, 0u, 0u};   // zero padding applies AFTER the prologue
+      *reinterpret_cast<u32x4*>(dst + u * 64 * PROW) = outv;
     }
   };
-  // weight tiles of one kernel row: `ntile` consecutive (chunk, tap) tiles starting at linear tile index t0
-  auto prefetch_w = [&](int t0, int ntile) {
+  // weight tiles of one kernel row: three consecutive (chunk, tap) tiles starting at linear tile index t0
+  auto prefetch_w = [&](int t0) {
+    const uint32_t so = wbase + (uint32_t)t0 * wtile_pack;
 #pragma unroll
-    for (int i = 0; i < WIT; ++i) {
-      const int off = (i * NTHREADS + tid) * 16;
-      const int tile = off / WTILE, inner = off - tile * WTILE;
-      wreg[i] = u32x4{0u, 0u, 0u, 0u};
-      if (tile < ntile) wreg[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(t0 + tile) * wtile_pack + inner);
-    }
+    for (int i = 0; i < WIT; ++i) wreg[i] = buf_load16(rsw, woff[i], so);
   };
   auto commit_w = [&](int buf) {
-    char* dst = wlds + buf * (3 * WTILE);
+    char* dst = wlds + buf * (3 * WTILE) + tid * 16;
 #pragma unroll
-    for (int i = 0; i < WIT; ++i) {
-      const int off = (i * NTHREADS + tid) * 16;
-      if (off < 3 * WTILE) *reinterpret_cast<u32x4*>(dst + off) = wreg[i];
-    }
+    for (int i = 0; i < WIT; ++i)
+      if ((i + 1) * NTHREADS * 16 <= 3 * WTILE || (i * NTHREADS + tid) * 16 < 3 * WTILE)
+        *reinterpret_cast<u32x4*>(dst + i * NTHREADS * 16) = wreg[i];
   };
-  auto mma_tap = [&](const char* pbase, int tapoff, const char* wt) {
+  auto mma_tap = [&](const char* pa_, const int (&ao)[MI], int aimm, const char* wt, const int (&bo)[NI]) {
     u32x4 a[MI], b[NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(pbase + arow[mi] + tapoff);
+    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(pa_ + ao[mi] + aimm);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(wt + brow[ni]);
+    for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(wt + bo[ni]);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], a[mi], b[ni], T());
+      for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], b[ni], a[mi], T());  // D rows = channels, cols = pixels
   };
 
   int gi = 0;  // kernel-row counter (weight buffer parity)
   if constexpr (KS == 3) {
+    int a1[MI], a2[MI];   // fragment row offsets of kernel rows 1 and 2 (row 0 = arow); kx is an immediate offset
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { a1[mi] = arow[mi] + p.PW * PROW; a2[mi] = arow[mi] + 2 * p.PW * PROW; }
     prefetch_patch(0, IC<0>());
-    prefetch_w(0, 3);
+    prefetch_w(0);
     for (int c = 0; c < p.nchunks; ++c) {
       if (c > 0) __syncthreads();           // every wave has finished reading the previous chunk's patch
       commit_patch(c, IC<0>());
@@ -250,12 +272,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky, ++gi) {
         commit_w(gi & 1);
-        __syncthreads();                    // patch + this row's weights visible; also orders buffer reuse (see header)
+        __syncthreads();                    // patch + this row's weights visible; also orders weight-buffer reuse
         const int nxt = c * 9 + (ky + 1) * 3;
-        if (nxt < p.nchunks * 9) prefetch_w(nxt, 3);
+        if (nxt < p.nchunks * 9) prefetch_w(nxt);
         const char* wt = wlds + (gi & 1) * (3 * WTILE);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) mma_tap(patch, (ky * p.PW + kx) * PROW, wt + kx * WTILE);
+        for (int kx = 0; kx < 3; ++kx) {
+          if (ky == 0) mma_tap(patch, arow, kx * PROW, wt + kx * WTILE, brow);
+          else if (ky == 1) mma_tap(patch, a1, kx * PROW, wt + kx * WTILE, brow);
+          else mma_tap(patch, a2, kx * PROW, wt + kx * WTILE, brow);
+        }
       }
     }
   } else {
@@ -266,7 +292,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
       prefetch_patch(3 * g, IC<0>());
       if (nn > 1) prefetch_patch(3 * g + 1, IC<1>());
       if (nn > 2) prefetch_patch(3 * g + 2, IC<2>());
-      prefetch_w(3 * g, nn);
+      prefetch_w(3 * g);
     };
     prefetch_group(0);
     for (int g = 0; g < ngroups; ++g, ++gi) {
@@ -279,103 +305,90 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
       __syncthreads();
       if (g + 1 < ngroups) prefetch_group(g + 1);
       const char* wt = wlds + (gi & 1) * (3 * WTILE);
-      mma_tap(patch, 0, wt);
-      if (nc > 1) mma_tap(patch + p.plane_bytes, 0, wt + WTILE);
-      if (nc > 2) mma_tap(patch + 2 * p.plane_bytes, 0, wt + 2 * WTILE);
+      mma_tap(patch, arow, 0, wt, brow);
+      if (nc > 1) mma_tap(patch + PLANE, arow, 0, wt + WTILE, brow);
+      if (nc > 2) mma_tap(patch + 2 * PLANE, arow, 0, wt + 2 * WTILE, brow);
     }
   }
-  __syncthreads();   // LDS is re-used by the epilogue
 
-  // ---------------- epilogue: acc -> LDS (wave-private fp32 tile) -> coalesced rows ----------------
-  constexpr int RP = WTM >= 32 ? 32 : 16;   // rows per pass
-  constexpr int MPP = RP / 16;              // mi tiles per pass
-  constexpr int SST = WTN + 4;              // padded row stride (floats): conflict-free 4-row-apart writes
-  float* stage = reinterpret_cast<float*>(smem) + wave * (RP * SST);
-  const int co_w = nt * BN + wn * WTN;      // first output channel of this wave
+  // ---------------- epilogue, straight from the accumulators ----------------
+  // MFMA rows are output channels and columns are pixels, so lane (lr, lq) holds, per 16x16 tile, the 4 consecutive
+  // channels 4*lq..4*lq+3 of pixel lr: one 8-byte (bf16) / 16-byte (fp32) NHWC store per tile, no LDS round trip.
+  const int co_w = nt * BN + wn * WTN + 4 * lq;   // first output channel of this lane
+  f32x4 bias4[NI];
 #pragma unroll
-  for (int pass = 0; pass < WTM / RP; ++pass) {
+  for (int ni = 0; ni < NI; ++ni) {
+    bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && p.out_mode == OUT_NHWC && co_w + ni * 16 < p.Cout) bias4[ni] = *reinterpret_cast<const f32x4*>(p.bias + co_w + ni * 16);
+  }
 #pragma unroll
-    for (int ml = 0; ml < MPP; ++ml)
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = wm * WTM + mi * 16 + lr;
+    const int tx = m & VWm, ty = (m >> p.lvw) & THm, g = m >> (p.lvw + p.lth);
+    const int n = n0 + g, y = y0 + ty, x = x0 + tx;
+    if (!(n < p.N && y < p.Ho && x < p.Wo)) continue;
+    const size_t opix = ((size_t)n * p.Ho + y) * p.Wo + x;
+    if (p.out_mode == OUT_NHWC) {
+      T* orow = reinterpret_cast<T*>(p.out) + opix * p.Cout + co_w;
+      const float* erow = p.emb ? p.emb + (size_t)n * p.emb_stride + co_w : nullptr;
+      size_t rpix = 0;
+      if (p.res_mode == RES_SAME) rpix = ((size_t)n * p.Hr + y) * p.Wr + x;
+      else if (p.res_mode == RES_UP2) rpix = ((size_t)n * p.Hr + (y >> 1)) * p.Wr + (x >> 1);
+      else if (p.res_mode == RES_POOL2) rpix = ((size_t)n * p.Hr + 2 * y) * p.Wr + 2 * x;
+      const T* rrow = reinterpret_cast<const T*>(p.res) + rpix * p.Cout + co_w;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (co_w + ni * 16 >= p.Cout) continue;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = acc[mi][ni][j] + bias4[ni][j];
+        if (erow) {
+          const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + ni * 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += ev[j];
+        }
+        if (p.res_mode != RES_NONE) {
+          auto ld4 = [&](const T* q, float (&d)[4]) {
+            if constexpr (E::DTYPE == 0) {
+              f32x4 t = *reinterpret_cast<const f32x4*>(q);
+              d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3];
+            } else {
+              bf16x4 t = *reinterpret_cast<const bf16x4*>(q);
+              d[0] = (float)t[0]; d[1] = (float)t[1]; d[2] = (float)t[2]; d[3] = (float)t[3];
+            }
+          };
+          float rv[4];
+          if (p.res_mode != RES_POOL2) {
+            ld4(rrow + ni * 16, rv);
+          } else {
+            float r0[4], r1[4], r2[4], r3[4];
+            const T* q = rrow + ni * 16;
+            ld4(q, r0); ld4(q + p.Cout, r1); ld4(q + (size_t)p.Wr * p.Cout, r2); ld4(q + (size_t)(p.Wr + 1) * p.Cout, r3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = 0.25f * ((r0[j] + r1[j]) + (r2[j] + r3[j]));
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += rv[j];
+        }
+        if constexpr (E::DTYPE == 0) {
+          *reinterpret_cast<f32x4*>(orow + ni * 16) = f32x4{o[0], o[1], o[2], o[3]};
+        } else {
+          bf16x4 t;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] = (bf16)o[j];
+          *reinterpret_cast<bf16x4*>(orow + ni * 16) = t;
+        }
+      }
+    } else {  // OUT_NCHW_F32 (network output): lanes lr are 16 consecutive pixels of a row -> 64-byte fp32 segments
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          stage[(ml * 16 + lq * 4 + r) * SST + ni * 16 + lr] = acc[pass * MPP + ml][ni][r];
-    __syncthreads();
-    if (p.out_mode == OUT_NHWC) {
-      constexpr int LPR = WTN / 4;          // lanes per row (4 channels each)
-      constexpr int RPI = 64 / LPR;         // rows per wave iteration
-      const int c4 = (lane % LPR) * 4, r_in = lane / LPR;
-      const int co = co_w + c4;
-      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias && co < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-#pragma unroll
-      for (int it = 0; it < RP / RPI; ++it) {
-        const int r = it * RPI + r_in;
-        const int m = wm * WTM + pass * RP + r;
-        const int tx = m & VWm, ty = (m >> p.lvw) & THm, g = m >> (p.lvw + p.lth);
-        const int n = n0 + g, y = y0 + ty, x = x0 + tx;
-        if (n < p.N && y < p.Ho && x < p.Wo && co < p.Cout) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * SST + c4);
-          float o[4] = {v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
-          if (p.emb) {
-            f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)n * p.emb_stride + co);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += ev[j];
-          }
-          if (p.res_mode != RES_NONE) {
-            const T* rp = reinterpret_cast<const T*>(p.res);
-            auto ld4 = [&](size_t pixel, float (&d)[4]) {
-              const T* q = rp + pixel * p.Cout + co;
-              if constexpr (E::DTYPE == 0) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(q);
-                d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3];
-              } else {
-                bf16x4 t = *reinterpret_cast<const bf16x4*>(q);
-                d[0] = (float)t[0]; d[1] = (float)t[1]; d[2] = (float)t[2]; d[3] = (float)t[3];
-              }
-            };
-            float rv[4];
-            if (p.res_mode == RES_SAME) {
-              ld4(((size_t)n * p.Hr + y) * p.Wr + x, rv);
-            } else if (p.res_mode == RES_UP2) {
-              ld4(((size_t)n * p.Hr + (y >> 1)) * p.Wr + (x >> 1), rv);
-            } else {
-              float r0[4], r1[4], r2[4], r3[4];
-              const size_t b0 = ((size_t)n * p.Hr + 2 * y) * p.Wr + 2 * x;
-              ld4(b0, r0); ld4(b0 + 1, r1); ld4(b0 + p.Wr, r2); ld4(b0 + p.Wr + 1, r3);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) rv[j] = 0.25f * ((r0[j] + r1[j]) + (r2[j] + r3[j]));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += rv[j];
-          }
-          T* op = reinterpret_cast<T*>(p.out) + (((size_t)n * p.Ho + y) * p.Wo + x) * p.Cout + co;
-          if constexpr (E::DTYPE == 0) {
-            *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
-          } else {
-            bf16x4 t;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = (bf16)o[j];
-            *reinterpret_cast<bf16x4*>(op) = t;
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int c = co_w + ni * 16 + r;
+          if (c < p.Cout)
+            reinterpret_cast<float*>(p.out)[(((size_t)n * p.Cout + c) * p.Ho + y) * p.Wo + x] = acc[mi][ni][r] + (p.bias ? p.bias[c] : 0.f);
         }
-      }
-    } else {  // OUT_NCHW_F32: few output channels (final conv), pixel-contiguous fp32 stores
-      const int ncol = min(WTN, p.Cout - co_w);
-      for (int idx = lane; idx < RP * ncol; idx += 64) {
-        const int r = idx % RP, cc = idx / RP;
-        const int m = wm * WTM + pass * RP + r;
-        const int tx = m & VWm, ty = (m >> p.lvw) & THm, g = m >> (p.lvw + p.lth);
-        const int n = n0 + g, y = y0 + ty, x = x0 + tx;
-        if (n < p.N && y < p.Ho && x < p.Wo) {
-          const int co = co_w + cc;
-          float v = stage[r * SST + cc] + (p.bias ? p.bias[co] : 0.f);
-          reinterpret_cast<float*>(p.out)[(((size_t)n * p.Cout + co) * p.Ho + y) * p.Wo + x] = v;
-        }
-      }
     }
-    __syncthreads();
   }
 }
 
@@ -419,7 +432,7 @@ int launch_cfg(const ConvKArgs& a, int BM, int BN, int ks, int pit, dim3 grid, s
 }
 
 struct Geo {
-  int Hc, Wc, Ho, Wo, BM, BN, bn_pack, lvw, lth, G, PW, PH, NP, tiles_x, tiles_y, groups, pad, stride, plane_bytes, pit;
+  int Hc, Wc, Ho, Wo, BM, BN, bn_pack, lvw, lth, G, PW, PH, NP, tiles_x, tiles_y, groups, pad, stride, plane_bytes, pit, pit_t;
   size_t lds;
 };
 
@@ -458,15 +471,12 @@ int compute_geo(const ConvDesc& d, Geo& g) {
   if (g.stride == 2) { g.PW = 2 * VW + 1; g.PH = 2 * THp + 1; }
   else { g.PW = VW + 2 * g.pad; g.PH = THp + 2 * g.pad; }
   g.NP = g.G * g.PH * g.PW;
-  g.plane_bytes = ((g.NP * PROW + 15) / 16) * 16;
   g.pit = (g.NP + 63) / 64;
+  g.pit_t = d.ks == 1 ? 2 : (g.pit <= 4 ? 4 : (g.pit <= 7 ? 7 : 11));   // template PIT actually launched
+  g.plane_bytes = g.pit_t * 64 * PROW;
   const int npl = d.ks == 1 ? 3 : 1;
   size_t main_lds = (size_t)npl * g.plane_bytes + 2 * 3 * (size_t)g.BN * 64;
-  const int WN = g.BN == 32 ? 1 : 2, WM = 4 / WN;
-  const int WTM = g.BM / WM, WTN = g.BN / WN;
-  const int RP = WTM >= 32 ? 32 : 16;
-  size_t epi_lds = (size_t)4 * RP * (WTN + 4) * 4;
-  g.lds = ((main_lds > epi_lds ? main_lds : epi_lds) + 15) / 16 * 16;
+  g.lds = (main_lds + 15) / 16 * 16;
   return 0;
 }
 
@@ -542,13 +552,19 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   a.mode = d.mode; a.pad = g.pad; a.stride = g.stride;
   a.pro_a = d.pro_a; a.pro_b = d.pro_b; a.pro_silu = d.pro_silu;
   a.w = d.w; a.bias = d.bias; a.Cout = d.Cout; a.bn_pack = g.bn_pack;
+  const size_t esz = d.dtype == 0 ? 4 : 2;
+  const size_t b0 = (size_t)d.N * d.Hs * d.Ws * d.C0 * esz, b1 = (size_t)d.N * d.Hs * d.Ws * d.C1 * esz;
+  const size_t wb = conv_packed_weight_bytes(d.dtype, d.Cout, Cin, d.ks);
+  MI355_REQUIRE(b0 < 0xFFFF0000ull && b1 < 0xFFFF0000ull && wb < 0xFFFF0000ull, -4,
+                "conv: a source tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
+  a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb;
   a.emb = d.emb; a.emb_stride = d.emb_stride;
   a.res = d.res; a.res_mode = d.res ? d.res_mode : RES_NONE;
   a.Hr = d.res_mode == RES_UP2 ? g.Ho / 2 : (d.res_mode == RES_POOL2 ? g.Ho * 2 : g.Ho);
   a.Wr = d.res_mode == RES_UP2 ? g.Wo / 2 : (d.res_mode == RES_POOL2 ? g.Wo * 2 : g.Wo);
   a.out = d.out; a.out_mode = d.out_mode;
   a.lvw = g.lvw; a.lth = g.lth; a.G = g.G; a.PW = g.PW; a.PH = g.PH; a.NP = g.NP;
-  a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.plane_bytes = g.plane_bytes;
+  a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
   dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
   int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, d.ks, g.pit, grid, g.lds, stream)
                         : launch_cfg<bf16>(a, g.BM, g.BN, d.ks, g.pit, grid, g.lds, stream);
