@@ -101,6 +101,8 @@ int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const fl
 // ---- sampler loops --------------------------------------------------------------------------------
 
 struct Scratch { float* t; float* v; float* none; char* unet_ws; int64_t unet_bytes; };
+// every image of a sampler step shares the step time: the engine computes ONE embedding row (stride-0 broadcast)
+struct UniformT { mi355_unet* n; explicit UniformT(mi355_unet* n_) : n(n_) { n->t_uniform = 1; } ~UniformT() { n->t_uniform = 0; } };
 static int carve(mi355_unet* net, int B, void* workspace, int64_t workspace_bytes, Scratch& sc) {
   MI355_REQUIRE(net && workspace, -1, "null argument");
   MI355_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, -1, "workspace must be 256-byte aligned");
@@ -122,6 +124,7 @@ int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const floa
   MI355_REQUIRE(x_channels == net->cfg.out_channels, -2, "cfm_euler_sample: the vector field must have the state's channel count");
   Scratch sc;
   if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
+  UniformT uniform_guard(net);
   hipStream_t s = S(stream);
   const int64_t n = (int64_t)batch * x_channels * net->cfg.image_size * net->cfg.image_size;
   if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -149,6 +152,7 @@ int mi355_ddpm_sample(mi355_unet* net, float* x, int channels, const float* cond
   MI355_REQUIRE(mode != MI355_DDPM_AMORTIZED || (amortized && cond), -2, "ddpm_sample: amortized needs a 2C-input net and a condition");
   Scratch sc;
   if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
+  UniformT uniform_guard(net);
   hipStream_t s = S(stream);
   const int64_t n = (int64_t)batch * channels * net->cfg.image_size * net->cfg.image_size;
   const int64_t n_al = (n + 3) / 4 * 4;

@@ -537,6 +537,10 @@ ConvGeom conv_geometry(const ConvDesc& d) {
 }
 
 int conv_launch(const ConvDesc& d, hipStream_t stream) {
+  {
+    const int r = conv1x1_try_launch(d, stream);
+    if (r <= 0) return r;
+  }
   const int CH = chunk_of(d.dtype);
   const int Cin = d.C0 + d.C1;
   MI355_REQUIRE(d.ks == 1 || d.ks == 3, -1, "conv: kernel size must be 1 or 3");

@@ -43,6 +43,8 @@ int conv_tile_n(int Cout);
 // host-side packing: w_host [Cout][Cin][ks][ks] fp32 (Cin = logical input channels; padded to a chunk)
 void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks, void* dst_host);
 int conv_launch(const ConvDesc& d, hipStream_t stream);
+// 1x1 GEMM with a stationary activation tile (conv1x1.hip): 0 = launched, 1 = not eligible, <0 = error
+int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream);
 
 // ---- GroupNorm statistics -> per-(n, channel) affine ----------------------------------------------
 // a[n,c] = rstd * gamma[c] (* (1 + film_scale)), b[n,c] = beta[c] - mean * rstd * gamma[c] (FiLM folded)

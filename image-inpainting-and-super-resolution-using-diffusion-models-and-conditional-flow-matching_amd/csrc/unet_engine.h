@@ -49,6 +49,7 @@ struct mi355_unet {
   // stats per image
   double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;
   int64_t launches = 0;
+  int t_uniform = 0;   // set by the sampler loops: t[0] holds for the whole batch
   // optional per-op profiling (mi355_unet_profile)
   std::vector<mi355_op_profile>* prof = nullptr;
   std::vector<hipEvent_t>* prof_events = nullptr;

@@ -407,10 +407,12 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
   };
   if (net->prof) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, stream); net->prof_events->push_back(e); }
   // time embedding path (fp32): emb2 = silu(time_embed(timestep_embedding(t))) ; embp = all emb_layers linears
-  if ((rc = timestep_embedding_launch(t, B, mc, 10000.f, F(l.temb), stream))) return rc;
-  if ((rc = linear_launch(F(l.temb), WF(net->te_w0), WF(net->te_b0), F(l.emb1), B, mc, 4 * mc, 0, 1, stream))) return rc;
-  if ((rc = linear_launch(F(l.emb1), WF(net->te_w2), WF(net->te_b2), F(l.emb2), B, 4 * mc, 4 * mc, 0, 1, stream))) return rc;
-  if ((rc = linear_launch(F(l.emb2), WF(net->emb_w), WF(net->emb_b), F(l.embp), B, 4 * mc, net->emb_total, 0, 0, stream))) return rc;
+  // in the sampler loops every image shares the step time: one embedding row, broadcast with stride 0
+  const int Be = net->t_uniform ? 1 : B, estride = net->t_uniform ? 0 : net->emb_total;
+  if ((rc = timestep_embedding_launch(t, Be, mc, 10000.f, F(l.temb), stream))) return rc;
+  if ((rc = linear_launch(F(l.temb), WF(net->te_w0), WF(net->te_b0), F(l.emb1), Be, mc, 4 * mc, 0, 1, stream))) return rc;
+  if ((rc = linear_launch(F(l.emb1), WF(net->te_w2), WF(net->te_b2), F(l.emb2), Be, 4 * mc, 4 * mc, 0, 1, stream))) return rc;
+  if ((rc = linear_launch(F(l.emb2), WF(net->emb_w), WF(net->emb_b), F(l.embp), Be, 4 * mc, net->emb_total, 0, 0, stream))) return rc;
   const int S = net->cfg.image_size;
   if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
   net->launches += 5;
@@ -422,7 +424,7 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
     if (op.kind == OP_GN) {
       GnDesc g; g.dtype = dtype; g.src0 = TP(op.src0); g.C0 = s0.C; g.src1 = TP(op.src1); g.C1 = C1;
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
-      if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = net->emb_total; }
+      if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = estride; }
       g.a = F(l.gna); g.b = F(l.gnb);
       rc = gn_affine_launch(g, stream);
       r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
@@ -432,7 +434,7 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
       c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks;
       if (op.use_pro) { c.pro_a = F(l.gna); c.pro_b = F(l.gnb); c.pro_silu = op.pro_silu; }
       c.w = W + op.w_off; c.bias = WF(op.bias_off); c.Cout = op.Cout;
-      if (op.emb_off >= 0) { c.emb = F(l.embp) + op.emb_off; c.emb_stride = net->emb_total; }
+      if (op.emb_off >= 0) { c.emb = F(l.embp) + op.emb_off; c.emb_stride = estride; }
       if (op.res >= 0) { c.res = TP(op.res); c.res_mode = op.res_mode; }
       c.out_mode = op.out_mode;
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;

@@ -403,3 +403,17 @@ if __name__ == "__main__":
     for g in gens:
         if not only or g.__name__ in only:
             g()
+
+
+def g_unet_keys():
+    """state_dict key order + shapes of the reference UNetModel for the three reference configs."""
+    out = {}
+    for name in ("cifar", "mnist", "flowers_in6", "tiny_noconvresample"):
+        kw, _, _ = UNET_CASES[name]
+        sd = make_unet(**kw).state_dict()
+        out[name] = [[k, list(v.shape)] for k, v in sd.items()]
+    save("unet_keys", keys=out)
+
+
+if __name__ == "__main__" and ("g_unet_keys" in sys.argv[1:] or len(sys.argv) == 1):
+    g_unet_keys()
