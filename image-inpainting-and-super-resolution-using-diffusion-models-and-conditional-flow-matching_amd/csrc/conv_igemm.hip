@@ -23,7 +23,6 @@
 namespace {
 
 constexpr int PROW = 96;   // bytes per patch pixel row in LDS (64 data + 32 pad)
-constexpr int NTHREADS = 256;
 
 struct ConvKArgs {
   const void* src0; const void* src1;
@@ -53,7 +52,9 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t v
 // KS: 3 (3x3) or 1 (1x1: three channel chunks play the role of the three taps of a kernel row)
 // PIT: 16-B patch fragments per thread per plane (compile-time bound of the staging loops)
 template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT>
-__global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
+__global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(ConvKArgs p) {
+  constexpr int NTHREADS = 64 * WM * WN;     // 4 or 8 waves; two workgroups per CU either way
+  constexpr int FR = NTHREADS / 4;          // patch pixels covered by one fragment sweep of the workgroup
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK, ESZ = sizeof(T);
   constexpr bool FAST = (E::DTYPE == 1);
@@ -61,8 +62,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
   constexpr int WTILE = BN * 64;             // bytes of one (chunk, tap) weight tile of this workgroup
   constexpr int WIT = (3 * WTILE + NTHREADS * 16 - 1) / (NTHREADS * 16);  // 16-B weight fragments per thread per kernel row
   constexpr int NPL = KS == 1 ? 3 : 1;       // patch planes
-  constexpr int PLANE = PIT * 64 * PROW;     // bytes per plane (every thread owns PIT fragment slots: no bounds checks)
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int PLANE = PIT * FR * PROW;     // bytes per plane (every thread owns PIT fragment slots: no bounds checks)
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* patch = smem;
   char* wlds = smem + NPL * PLANE;           // two buffers of 3*WTILE
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
     const int cy0 = y0 * p.stride - p.pad, cx0 = x0 * p.stride - p.pad;
 #pragma unroll
     for (int u = 0; u < PIT; ++u) {
-      const int i = frow + u * 64;
+      const int i = frow + u * FR;
       int s = -1;
       if (i < p.NP) {
         const int g = i / pimg, r = i - g * pimg;
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
     char* dst = patch + pl * PLANE + frow * PROW + fq * 16;
     if (pro == 0 && prefetchable) {
 #pragma unroll
-      for (int u = 0; u < PIT; ++u) *reinterpret_cast<u32x4*>(dst + u * 64 * PROW) = raw[pl][u];
+      for (int u = 0; u < PIT; ++u) *reinterpret_cast<u32x4*>(dst + u * FR * PROW) = raw[pl][u];
       return;
     }
     const int cb = c * CHUNK;
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
 #pragma unroll
       for (int j = 0; j < V; ++j) { av[j] = pa[pl][j]; bv[j] = pb[pl][j]; }
       if (pro && !single && sidx[u] >= 0) {
-        const int n = n0 + (frow + u * 64) / pimg;
+        const int n = n0 + (frow + u * FR) / pimg;
         const float* ga = p.pro_a + (size_t)n * p.Cin + cb + fq * V;
         const float* gb = p.pro_b + (size_t)n * p.Cin + cb + fq * V;
 #pragma unroll
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(ConvKArgs p) {
       }
       u32x4 outv = float_to_frag(f, T());
       if (!((vmask >> u) & 1u)) outv = u32x4{0u, 0u, 0u, 0u};   // zero padding applies AFTER the prologue
-      *reinterpret_cast<u32x4*>(dst + u * 64 * PROW) = outv;
+      *reinterpret_cast<u32x4*>(dst + u * FR * PROW) = outv;
     }
   };
   // weight tiles of one kernel row: three consecutive (chunk, tap) tiles starting at linear tile index t0
@@ -401,20 +402,17 @@ int launch_t(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     if (e != hipSuccess) { (void)hipGetLastError(); }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
   return 0;
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-int launch_ks(const ConvKArgs& a, int ks, int pit, dim3 grid, size_t lds, hipStream_t s) {
-  if (ks == 1) {
-    if (pit <= 2) return launch_t<T, BM, BN, WM, WN, 1, 2>(a, grid, lds, s);
-    mi355_set_error("conv: 1x1 patch too large");
-    return -4;
-  }
-  if (pit <= 4) return launch_t<T, BM, BN, WM, WN, 3, 4>(a, grid, lds, s);
-  if (pit <= 7) return launch_t<T, BM, BN, WM, WN, 3, 7>(a, grid, lds, s);
-  if (pit <= 11) return launch_t<T, BM, BN, WM, WN, 3, 11>(a, grid, lds, s);
+int launch_ks(const ConvKArgs& a, int ks, int pit_t, dim3 grid, size_t lds, hipStream_t s) {
+  constexpr int W8 = WM * WN == 8;
+  if (ks == 1) return launch_t<T, BM, BN, WM, WN, 1, W8 ? 1 : 2>(a, grid, lds, s);
+  if (pit_t == (W8 ? 2 : 4)) return launch_t<T, BM, BN, WM, WN, 3, W8 ? 2 : 4>(a, grid, lds, s);
+  if (pit_t == (W8 ? 4 : 7)) return launch_t<T, BM, BN, WM, WN, 3, W8 ? 4 : 7>(a, grid, lds, s);
+  if (pit_t == (W8 ? 6 : 11)) return launch_t<T, BM, BN, WM, WN, 3, W8 ? 6 : 11>(a, grid, lds, s);
   mi355_set_error("conv: patch too large");
   return -4;
 }
@@ -471,9 +469,13 @@ int compute_geo(const ConvDesc& d, Geo& g) {
   if (g.stride == 2) { g.PW = 2 * VW + 1; g.PH = 2 * THp + 1; }
   else { g.PW = VW + 2 * g.pad; g.PH = THp + 2 * g.pad; }
   g.NP = g.G * g.PH * g.PW;
-  g.pit = (g.NP + 63) / 64;
-  g.pit_t = d.ks == 1 ? 2 : (g.pit <= 4 ? 4 : (g.pit <= 7 ? 7 : 11));   // template PIT actually launched
-  g.plane_bytes = g.pit_t * 64 * PROW;
+  const bool w8 = false;   // 8-wave (512-thread) tiles are supported by the kernel template but lose to 4 waves: 128 VGPRs spill
+  const int fr = w8 ? 128 : 64;                 // patch pixels per fragment sweep
+  g.pit = (g.NP + fr - 1) / fr;
+  if (d.ks == 1) g.pit_t = w8 ? 1 : 2;          // template PIT actually launched
+  else if (w8) g.pit_t = g.pit <= 2 ? 2 : (g.pit <= 4 ? 4 : 6);
+  else g.pit_t = g.pit <= 4 ? 4 : (g.pit <= 7 ? 7 : 11);
+  g.plane_bytes = g.pit_t * fr * PROW;
   const int npl = d.ks == 1 ? 3 : 1;
   size_t main_lds = (size_t)npl * g.plane_bytes + 2 * 3 * (size_t)g.BN * 64;
   g.lds = (main_lds + 15) / 16 * 16;
@@ -550,6 +552,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   MI355_REQUIRE(d.mode != CONV_POOL2 || (d.Hs % 2 == 0 && d.Ws % 2 == 0), -2, "conv: avg-pool gather needs even size");
   Geo g; compute_geo(d, g);
   MI355_REQUIRE(g.lds <= 160 * 1024, -4, "conv: LDS budget exceeded");
+  MI355_REQUIRE(g.pit <= g.pit_t, -4, "conv: input patch too large for the staging loops");
   ConvKArgs a;
   a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = Cin / CH;
   a.N = d.N; a.Hs = d.Hs; a.Ws = d.Ws; a.Hc = g.Hc; a.Wc = g.Wc; a.Ho = g.Ho; a.Wo = g.Wo;
@@ -570,8 +573,8 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   a.lvw = g.lvw; a.lth = g.lth; a.G = g.G; a.PW = g.PW; a.PH = g.PH; a.NP = g.NP;
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
   dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
-  int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, d.ks, g.pit, grid, g.lds, stream)
-                        : launch_cfg<bf16>(a, g.BM, g.BN, d.ks, g.pit, grid, g.lds, stream);
+  int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream)
+                        : launch_cfg<bf16>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream);
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
