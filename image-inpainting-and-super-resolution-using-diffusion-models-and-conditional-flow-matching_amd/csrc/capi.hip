@@ -1,5 +1,6 @@
 // extern "C" boundary of libmi355_sampler.so (see include/mi355_sampler.h) and the sampler loops.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -281,9 +282,30 @@ int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, fl
   const bool nhwc = cout % 4 == 0;
   d.out_mode = nhwc ? OUT_NHWC : OUT_NCHW_F32;
   d.out = nhwc ? yout : (void*)y;
+#ifdef CONV_STAMPS
+  const size_t nwaves = (size_t)g.grid_m * g.grid_n * 4;
+  MI355_REQUIRE(p + nwaves * 64 <= end, -2, "conv2d: workspace too small (stamps)");
+  MI355_CHECK_HIP(hipMemsetAsync(p, 0, nwaves * 64, s));
+  d.dbg = p;
+#endif
   if ((rc = conv_launch(d, s))) return rc;
   if (nhwc && (rc = unpack_nchw_launch(dtype, yout, batch, g.Ho * g.Wo, cout, y, s))) return rc;
   MI355_CHECK_HIP(hipStreamSynchronize(s));  // `packed` is a temporary host buffer
+#ifdef CONV_STAMPS
+  {
+    std::vector<unsigned long long> hv(nwaves * 8);
+    MI355_CHECK_HIP(hipMemcpy(hv.data(), p, nwaves * 64, hipMemcpyDeviceToHost));
+    static const char* names[8] = {"setup", "commit_patch", "barrier_A", "commit_w(+vmcnt)", "barrier_B", "prefetch_issue", "mma", "epilogue"};
+    double h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
+    for (size_t w = 0; w < nwaves; ++w) for (int k = 0; k < 8; ++k) h[k] += (double)hv[w * 8 + k];
+    for (int k = 0; k < 8; ++k) tot += h[k];
+    if (tot > 0) {
+      fprintf(stderr, "[conv stamps] waves %zu, cycles/wave %.0f:", nwaves, tot / nwaves);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f (%.1f%%)", names[k], h[k] / nwaves, 100.0 * h[k] / tot);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return 0;
 }
 

@@ -18,6 +18,8 @@
 //     kernel row's weight tiles are loaded into registers while the current row's MFMAs run; weight
 //     tiles are double-buffered in LDS, so there is one barrier per kernel row (48 MFMAs per wave).
 // 4 waves per workgroup, v_mfma_f32_16x16x32_bf16 (or v_mfma_f32_16x16x4_f32 in the fp32 build).
+#include <cstdlib>
+
 #include "ops.h"
 
 namespace {
@@ -36,7 +38,28 @@ struct ConvKArgs {
   void* out; int out_mode;
   int lvw, lth, G, PW, PH, NP, tiles_x, tiles_y;
   uint32_t bytes0, bytes1, wbytes;   // buffer sizes (raw buffer descriptors: out-of-range loads return 0)
+  unsigned long long* dbg;           // diagnostic build only (-DCONV_STAMPS): per-phase cycle sums
+  int ablate;                        // diagnostic build only: 1 = no output stores, 2 = no prologue math, 4 = no MFMA
+  int stagger;                       // odd-slot workgroup start delay in units of s_sleep(127) (~8k cycles each)
 };
+
+#ifdef CONV_STAMPS
+// In-kernel phase stamps (cdna_hip_programming.md section 7): diagnostic build only, never the timed build.
+__device__ __forceinline__ unsigned long long conv_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP_DECL unsigned long long st_prev = conv_stamp(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(k) { const unsigned long long st_now = conv_stamp(); st_acc[k] += st_now - st_prev; st_prev = st_now; }
+#define STAMP_FLUSH if (p.dbg && (threadIdx.x & 63) == 0) { unsigned long long* q = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6)) * 8; for (int k = 0; k < 8; ++k) q[k] = st_acc[k]; }
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
+#endif
 
 template <int I> struct IC { static constexpr int value = I; };
 
@@ -51,7 +74,8 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t v
 
 // KS: 3 (3x3) or 1 (1x1: three channel chunks play the role of the three taps of a kernel row)
 // PIT: 16-B patch fragments per thread per plane (compile-time bound of the staging loops)
-template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT>
+// MULTI: the tile spans several (small) images, so the prologue's (a, b) differ per patch fragment
+template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT, bool MULTI>
 __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(ConvKArgs p) {
   constexpr int NTHREADS = 64 * WM * WN;     // 4 or 8 waves; two workgroups per CU either way
   constexpr int FR = NTHREADS / 4;          // patch pixels covered by one fragment sweep of the workgroup
@@ -92,13 +116,15 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
   uint32_t vmask = 0;
   {
     const int cy0 = y0 * p.stride - p.pad, cx0 = x0 * p.stride - p.pad;
+    const float inv_pimg = 1.0f / (float)pimg, inv_pw = 1.0f / (float)p.PW;
 #pragma unroll
     for (int u = 0; u < PIT; ++u) {
       const int i = frow + u * FR;
       int s = -1;
       if (i < p.NP) {
-        const int g = i / pimg, r = i - g * pimg;
-        const int py = r / p.PW, px = r - py * p.PW;
+        // i < 65536 and the divisors are small: floor((i + 0.5) / d) in fp32 is exact and costs 3 instructions
+        const int g = (int)(((float)i + 0.5f) * inv_pimg), r = i - g * pimg;
+        const int py = (int)(((float)r + 0.5f) * inv_pw), px = r - py * p.PW;
         const int n = n0 + g, cy = cy0 + py, cx = cx0 + px;
         if (n < p.N && cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
           if (p.mode == CONV_UP2) s = (n * p.Hs + (cy >> 1)) * p.Ws + (cx >> 1);
@@ -142,18 +168,25 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     const uint32_t tile = off / WTILE, inner = off - tile * WTILE;
     woff[i] = off < 3 * WTILE ? tile * wtile_pack + inner : p.wbytes;
   }
-  const bool single = p.G == 1;   // whole tile inside one image: the prologue's (a, b) are per-thread constants per chunk
   const bool prefetchable = p.mode != CONV_POOL2;
+#ifdef CONV_STAMPS
+  const int pro = (p.pro_a == nullptr || (p.ablate & 2)) ? 0 : (p.pro_silu ? 2 : 1);
+#else
   const int pro = p.pro_a == nullptr ? 0 : (p.pro_silu ? 2 : 1);
+#endif
 
   u32x4 raw[NPL][PIT];
   u32x4 wreg[WIT];
-  float pa[NPL][V], pb[NPL][V];
+  constexpr int NAB = MULTI ? PIT : 1;   // (a, b) register sets per plane
+  float pa[NPL][NAB][V], pb[NPL][NAB][V];
 
   // issue the global loads of chunk c into plane register set PL (no waits).  PL is a compile-time constant and
   // no pointer to a register array is ever formed: either would push the arrays into scratch memory.
   auto prefetch_patch = [&](int c, auto plc) {
     constexpr int pl = decltype(plc)::value;
+#ifdef CONV_STAMPS
+    if (p.ablate & 16) return;
+#endif
     const int cb = c * CHUNK;
     if (prefetchable) {
       if (cb < p.C0) {
@@ -170,16 +203,25 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
         for (int u = 0; u < PIT; ++u) raw[pl][u] = buf_load16(rs1, voff[u], so);
       }
     }
-    if (pro && single) {
-      const float* ap = p.pro_a + (size_t)n0 * p.Cin + cb + fq * V;
-      const float* bp = p.pro_b + (size_t)n0 * p.Cin + cb + fq * V;
+    if (pro) {   // prologue affine of this chunk's channels, prefetched with the data (never loaded inside commit_patch:
+                 // a load there would force the compiler to drain vmcnt, i.e. to wait for the weight prefetch too)
 #pragma unroll
-      for (int j = 0; j < V; ++j) { pa[pl][j] = ap[j]; pb[pl][j] = bp[j]; }
+      for (int k = 0; k < NAB; ++k) {
+        int n = n0;
+        if (MULTI) n = min(n0 + (int)(((float)(frow + k * FR) + 0.5f) * (1.0f / (float)pimg)), p.N - 1);
+        const float* ap = p.pro_a + (size_t)n * p.Cin + cb + fq * V;
+        const float* bp = p.pro_b + (size_t)n * p.Cin + cb + fq * V;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { pa[pl][k][j] = ap[j]; pb[pl][k][j] = bp[j]; }
+      }
     }
   };
   // transform + write chunk c (register set PL) into LDS plane PL
   auto commit_patch = [&](int c, auto plc) {
     constexpr int pl = decltype(plc)::value;
+#ifdef CONV_STAMPS
+    if (p.ablate & 16) return;
+#endif
     char* dst = patch + pl * PLANE + frow * PROW + fq * 16;
     if (pro == 0 && prefetchable) {
 #pragma unroll
@@ -191,14 +233,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     for (int u = 0; u < PIT; ++u) {
       float av[V], bv[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) { av[j] = pa[pl][j]; bv[j] = pb[pl][j]; }
-      if (pro && !single && sidx[u] >= 0) {
-        const int n = n0 + (frow + u * FR) / pimg;
-        const float* ga = p.pro_a + (size_t)n * p.Cin + cb + fq * V;
-        const float* gb = p.pro_b + (size_t)n * p.Cin + cb + fq * V;
-#pragma unroll
-        for (int j = 0; j < V; ++j) { av[j] = ga[j]; bv[j] = gb[j]; }
-      }
+      for (int j = 0; j < V; ++j) { av[j] = pa[pl][MULTI ? u : 0][j]; bv[j] = pb[pl][MULTI ? u : 0][j]; }
       float f[V];
       auto xform = [&](const u32x4& rw, float (&o)[V]) {
         frag_to_float(rw, o, T());
@@ -236,11 +271,17 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
   };
   // weight tiles of one kernel row: three consecutive (chunk, tap) tiles starting at linear tile index t0
   auto prefetch_w = [&](int t0) {
+#ifdef CONV_STAMPS
+    if (p.ablate & 8) return;
+#endif
     const uint32_t so = wbase + (uint32_t)t0 * wtile_pack;
 #pragma unroll
     for (int i = 0; i < WIT; ++i) wreg[i] = buf_load16(rsw, woff[i], so);
   };
   auto commit_w = [&](int buf) {
+#ifdef CONV_STAMPS
+    if (p.ablate & 8) return;
+#endif
     char* dst = wlds + buf * (3 * WTILE) + tid * 16;
 #pragma unroll
     for (int i = 0; i < WIT; ++i)
@@ -249,33 +290,55 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
   };
   auto mma_tap = [&](const char* pa_, const int (&ao)[MI], int aimm, const char* wt, const int (&bo)[NI]) {
     u32x4 a[MI], b[NI];
+#ifdef CONV_STAMPS
+    if (p.ablate & 32) return;
+#endif
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(pa_ + ao[mi] + aimm);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(wt + bo[ni]);
+#ifdef CONV_STAMPS
+    if (p.ablate & 4) { asm volatile("" ::"v"(a[0]), "v"(b[0])); return; }
+#endif
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], b[ni], a[mi], T());  // D rows = channels, cols = pixels
+    __builtin_amdgcn_s_setprio(0);
   };
 
   int gi = 0;  // kernel-row counter (weight buffer parity)
+  // Two workgroups share a CU and would otherwise run their staging / MFMA / store phases in lockstep (measured: the
+  // phase costs simply add up).  Delaying the workgroup in the odd threadgroup slot of the CU (HW_ID.TG_ID, bits 19:16)
+  // by about half a chunk period puts one workgroup's MFMA rows beside the other's VALU/LDS/memory phases.
+  if (p.stagger > 0 && ((__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4) & 1) != 0)) {
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  STAMP_DECL
   if constexpr (KS == 3) {
     int a1[MI], a2[MI];   // fragment row offsets of kernel rows 1 and 2 (row 0 = arow); kx is an immediate offset
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) { a1[mi] = arow[mi] + p.PW * PROW; a2[mi] = arow[mi] + 2 * p.PW * PROW; }
     prefetch_patch(0, IC<0>());
     prefetch_w(0);
+    STAMP(0)
     for (int c = 0; c < p.nchunks; ++c) {
       if (c > 0) __syncthreads();           // every wave has finished reading the previous chunk's patch
+      STAMP(2)
       commit_patch(c, IC<0>());
+      STAMP(1)
       if (c + 1 < p.nchunks) prefetch_patch(c + 1, IC<0>());
+      STAMP(5)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky, ++gi) {
         commit_w(gi & 1);
+        STAMP(3)
         __syncthreads();                    // patch + this row's weights visible; also orders weight-buffer reuse
+        STAMP(4)
         const int nxt = c * 9 + (ky + 1) * 3;
         if (nxt < p.nchunks * 9) prefetch_w(nxt);
+        STAMP(5)
         const char* wt = wlds + (gi & 1) * (3 * WTILE);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -283,6 +346,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
           else if (ky == 1) mma_tap(patch, a1, kx * PROW, wt + kx * WTILE, brow);
           else mma_tap(patch, a2, kx * PROW, wt + kx * WTILE, brow);
         }
+        STAMP(6)
       }
     }
   } else {
@@ -371,6 +435,9 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] += rv[j];
         }
+#ifdef CONV_STAMPS
+        if (p.ablate & 1) { if (o[0] == 12345.678f) orow[0] = (T)o[1]; continue; }
+#endif
         if constexpr (E::DTYPE == 0) {
           *reinterpret_cast<f32x4*>(orow + ni * 16) = f32x4{o[0], o[1], o[2], o[3]};
         } else {
@@ -391,11 +458,13 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
         }
     }
   }
+  STAMP(7)
+  STAMP_FLUSH
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT>
-int launch_t(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, KS, PIT>;
+template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT, bool MULTI>
+int launch_m(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, KS, PIT, MULTI>;
   static bool attr_done = false;  // allow > 64 KB of dynamic LDS (the CU has 160 KB)
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -404,6 +473,13 @@ int launch_t(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
   return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT>
+int launch_t(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  if constexpr (BM == 64) { if (a.G > 1) return launch_m<T, BM, BN, WM, WN, KS, PIT, true>(a, grid, lds, s); }
+  if (a.G > 1) { mi355_set_error("conv: multi-image tiles need the 64-pixel tile"); return -4; }
+  return launch_m<T, BM, BN, WM, WN, KS, PIT, false>(a, grid, lds, s);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -451,7 +527,9 @@ int compute_geo(const ConvDesc& d, Geo& g) {
   cand[nc][0] = 64; cand[nc++][1] = P;
   if (Q != P) { cand[nc][0] = 64; cand[nc++][1] = Q; }
   int bestBM = cand[nc - 1][0], bestBN = cand[nc - 1][1];
+  const long img_slots = (long)(1 << ilog2_ceil(g.Wo)) * (1 << ilog2_ceil(g.Ho));
   for (int i = 0; i < nc; ++i) {
+    if (cand[i][0] == 128 && img_slots < 128) continue;   // several images per tile: only the 64-pixel tile has that variant
     const long wgs = ((M + cand[i][0] - 1) / cand[i][0]) * ((d.Cout + cand[i][1] - 1) / cand[i][1]);
     if (wgs >= 512) { bestBM = cand[i][0]; bestBN = cand[i][1]; break; }
   }
@@ -565,6 +643,9 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   MI355_REQUIRE(b0 < 0xFFFF0000ull && b1 < 0xFFFF0000ull && wb < 0xFFFF0000ull, -4,
                 "conv: a source tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb;
+  a.dbg = reinterpret_cast<unsigned long long*>(d.dbg);
+  { static const int stg = getenv("MI355_CONV_STAGGER") ? atoi(getenv("MI355_CONV_STAGGER")) : 0; a.stagger = stg; }
+  { static const int abl = getenv("MI355_CONV_ABLATE") ? atoi(getenv("MI355_CONV_ABLATE")) : 0; a.ablate = abl; }
   a.emb = d.emb; a.emb_stride = d.emb_stride;
   a.res = d.res; a.res_mode = d.res ? d.res_mode : RES_NONE;
   a.Hr = d.res_mode == RES_UP2 ? g.Ho / 2 : (d.res_mode == RES_POOL2 ? g.Ho * 2 : g.Ho);

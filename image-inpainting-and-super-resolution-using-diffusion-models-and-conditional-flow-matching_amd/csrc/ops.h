@@ -29,6 +29,7 @@ struct ConvDesc {
   const float* emb = nullptr; int emb_stride = 0;   // per-(n, co) additive term (ResBlock emb_layers)
   const void* res = nullptr; int res_mode = RES_NONE;  // residual NHWC tensor with Cout channels
   void* out = nullptr; int out_mode = OUT_NHWC;
+  void* dbg = nullptr;                      // diagnostic builds only (-DCONV_STAMPS): 9 x u64 phase-cycle sums
 };
 
 struct ConvGeom {

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-LIB_PATH = os.path.join(CSRC, "libmi355_sampler.so")
+LIB_PATH = os.environ.get("MI355_SAMPLER_LIB") or os.path.join(CSRC, "libmi355_sampler.so")
 
 MI355_F32, MI355_BF16 = 0, 1
 DDPM_PRIOR, DDPM_AMORTIZED, DDPM_REPLACEMENT, DDIM = 0, 1, 2, 3
