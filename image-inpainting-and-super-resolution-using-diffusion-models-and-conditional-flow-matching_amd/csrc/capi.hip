@@ -252,7 +252,9 @@ int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, fl
   const int CH = dtype == 0 ? 16 : 32, esz = dtype == 0 ? 4 : 2;
   const int cpad = (cin + CH - 1) / CH * CH;
   ConvDesc d; d.dtype = dtype; d.N = batch; d.Hs = h; d.Ws = w; d.C0 = cpad; d.ks = ksize; d.Cout = cout;
-  d.mode = stride == 2 ? CONV_STRIDE2 : (resample == 2 ? CONV_UP2 : (resample == 3 ? CONV_POOL2 : CONV_UNIT));
+  const bool pool = resample == 3;   // 2x2 average pool of the (normalised) input: a pre-pass, then a plain conv
+  if (pool) { d.Hs = h / 2; d.Ws = w / 2; }
+  d.mode = stride == 2 ? CONV_STRIDE2 : (resample == 2 ? CONV_UP2 : CONV_UNIT);
   const ConvGeom g = conv_geometry(d);
   char* p = reinterpret_cast<char*>(workspace);
   char* end = p + workspace_bytes;
@@ -263,6 +265,7 @@ int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, fl
   float* gb = reinterpret_cast<float*>(p); p += al256((size_t)batch * cpad * 4);
   float* gpad = reinterpret_cast<float*>(p); p += 2 * al256((size_t)cpad * 4);
   void* yout = p; p += al256((size_t)batch * g.Ho * g.Wo * cout * esz);
+  void* xpool = p; if (pool) p += al256((size_t)batch * (h / 2) * (w / 2) * cpad * esz);
   MI355_REQUIRE(p <= end, -2, "conv2d: workspace too small");
   int rc;
   if ((rc = pack_nhwc_launch(dtype, x, cin, nullptr, 0, batch, h * w, cpad, xin, s))) return rc;
@@ -276,9 +279,13 @@ int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, fl
     gd.a = ga; gd.b = gb;
     (void)gpad;
     if ((rc = gn_affine_launch(gd, s))) return rc;
-    d.pro_a = ga; d.pro_b = gb; d.pro_silu = gn_silu;
+    if (!pool) { d.pro_a = ga; d.pro_b = gb; d.pro_silu = gn_silu; }
   }
-  d.src0 = xin; d.w = wdev; d.bias = bias_host ? bdev : nullptr;
+  d.src0 = xin;
+  if (pool) {
+    if ((rc = affine_pool_launch(dtype, xin, gn_gamma ? ga : nullptr, gn_gamma ? gb : nullptr, gn_silu, xpool, batch, h, w, cpad, s))) return rc;
+    d.src0 = xpool;
+  } d.w = wdev; d.bias = bias_host ? bdev : nullptr;
   const bool nhwc = cout % 4 == 0;
   d.out_mode = nhwc ? OUT_NHWC : OUT_NCHW_F32;
   d.out = nhwc ? yout : (void*)y;

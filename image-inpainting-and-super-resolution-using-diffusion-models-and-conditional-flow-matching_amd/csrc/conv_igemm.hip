@@ -19,6 +19,7 @@
 //     tiles are double-buffered in LDS, so there is one barrier per kernel row (48 MFMAs per wave).
 // 4 waves per workgroup, v_mfma_f32_16x16x32_bf16 (or v_mfma_f32_16x16x4_f32 in the fp32 build).
 #include <cstdlib>
+#include <type_traits>
 
 #include "ops.h"
 
@@ -37,7 +38,7 @@ struct ConvKArgs {
   const void* res; int res_mode; int Hr, Wr;
   void* out; int out_mode;
   int lvw, lth, G, PW, PH, NP, tiles_x, tiles_y;
-  uint32_t bytes0, bytes1, wbytes;   // buffer sizes (raw buffer descriptors: out-of-range loads return 0)
+  uint32_t bytes0, bytes1, wbytes, obytes, rbytes;   // buffer sizes (raw buffer descriptors: out-of-range loads return 0, stores drop)
   unsigned long long* dbg;           // diagnostic build only (-DCONV_STAMPS): per-phase cycle sums
   int ablate;                        // diagnostic build only: 1 = no output stores, 2 = no prologue math, 4 = no MFMA
   int stagger;                       // odd-slot workgroup start delay in units of s_sleep(127) (~8k cycles each)
@@ -128,7 +129,6 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
         const int n = n0 + g, cy = cy0 + py, cx = cx0 + px;
         if (n < p.N && cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
           if (p.mode == CONV_UP2) s = (n * p.Hs + (cy >> 1)) * p.Ws + (cx >> 1);
-          else if (p.mode == CONV_POOL2) s = (n * p.Hs + 2 * cy) * p.Ws + 2 * cx;
           else s = (n * p.Hs + cy) * p.Ws + cx;
         }
       }
@@ -168,7 +168,6 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     const uint32_t tile = off / WTILE, inner = off - tile * WTILE;
     woff[i] = off < 3 * WTILE ? tile * wtile_pack + inner : p.wbytes;
   }
-  const bool prefetchable = p.mode != CONV_POOL2;
 #ifdef CONV_STAMPS
   const int pro = (p.pro_a == nullptr || (p.ablate & 2)) ? 0 : (p.pro_silu ? 2 : 1);
 #else
@@ -188,7 +187,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     if (p.ablate & 16) return;
 #endif
     const int cb = c * CHUNK;
-    if (prefetchable) {
+    {
       if (cb < p.C0) {
         const uint32_t so = cb * ESZ;
 #pragma unroll
@@ -223,7 +222,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     if (p.ablate & 16) return;
 #endif
     char* dst = patch + pl * PLANE + frow * PROW + fq * 16;
-    if (pro == 0 && prefetchable) {
+    if (pro == 0) {
 #pragma unroll
       for (int u = 0; u < PIT; ++u) *reinterpret_cast<u32x4*>(dst + u * FR * PROW) = raw[pl][u];
       return;
@@ -245,25 +244,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
           for (int j = 0; j < V; ++j) o[j] = av[j] * o[j] + bv[j];
         }
       };
-      if (prefetchable) {
-        xform(raw[pl][u], f);
-      } else {  // 2x2 average pool of the transformed source (ResBlock down=True): rare, plain loads
-#pragma unroll
-        for (int j = 0; j < V; ++j) f[j] = 0.f;
-        if (sidx[u] >= 0) {
-          const bool from0 = cb < p.C0;
-          const T* sp = from0 ? reinterpret_cast<const T*>(p.src0) + cb : reinterpret_cast<const T*>(p.src1) + (cb - p.C0);
-          const int Cs = from0 ? p.C0 : p.C1;
-          const T* ptr = sp + (size_t)sidx[u] * Cs + fq * V;
-          float t0[V], t1[V], t2[V], t3[V];
-          xform(*reinterpret_cast<const u32x4*>(ptr), t0);
-          xform(*reinterpret_cast<const u32x4*>(ptr + Cs), t1);
-          xform(*reinterpret_cast<const u32x4*>(ptr + (size_t)p.Ws * Cs), t2);
-          xform(*reinterpret_cast<const u32x4*>(ptr + (size_t)(p.Ws + 1) * Cs), t3);
-#pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = 0.25f * ((t0[j] + t1[j]) + (t2[j] + t3[j]));
-        }
-      }
+      xform(raw[pl][u], f);
       u32x4 outv = float_to_frag(f, T());
       if (!((vmask >> u) & 1u)) outv = u32x4{0u, 0u, 0u, 0u};   // zero padding applies AFTER the prologue
       *reinterpret_cast<u32x4*>(dst + u * FR * PROW) = outv;
@@ -379,82 +360,98 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
   // ---------------- epilogue, straight from the accumulators ----------------
   // MFMA rows are output channels and columns are pixels, so lane (lr, lq) holds, per 16x16 tile, the 4 consecutive
   // channels 4*lq..4*lq+3 of pixel lr: one 8-byte (bf16) / 16-byte (fp32) NHWC store per tile, no LDS round trip.
+  // Every load of the epilogue (bias, emb, residual) is issued before the first use, and invalid pixels are steered
+  // out of the buffer range (loads return 0, stores are dropped), so there is no branch and no per-tile latency chain.
   const int co_w = nt * BN + wn * WTN + 4 * lq;   // first output channel of this lane
-  f32x4 bias4[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && p.out_mode == OUT_NHWC && co_w + ni * 16 < p.Cout) bias4[ni] = *reinterpret_cast<const f32x4*>(p.bias + co_w + ni * 16);
-  }
+  int pn[MI], py_[MI], px_[MI]; bool pvalid[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = wm * WTM + mi * 16 + lr;
     const int tx = m & VWm, ty = (m >> p.lvw) & THm, g = m >> (p.lvw + p.lth);
-    const int n = n0 + g, y = y0 + ty, x = x0 + tx;
-    if (!(n < p.N && y < p.Ho && x < p.Wo)) continue;
-    const size_t opix = ((size_t)n * p.Ho + y) * p.Wo + x;
-    if (p.out_mode == OUT_NHWC) {
-      T* orow = reinterpret_cast<T*>(p.out) + opix * p.Cout + co_w;
-      const float* erow = p.emb ? p.emb + (size_t)n * p.emb_stride + co_w : nullptr;
-      size_t rpix = 0;
-      if (p.res_mode == RES_SAME) rpix = ((size_t)n * p.Hr + y) * p.Wr + x;
-      else if (p.res_mode == RES_UP2) rpix = ((size_t)n * p.Hr + (y >> 1)) * p.Wr + (x >> 1);
-      else if (p.res_mode == RES_POOL2) rpix = ((size_t)n * p.Hr + 2 * y) * p.Wr + 2 * x;
-      const T* rrow = reinterpret_cast<const T*>(p.res) + rpix * p.Cout + co_w;
+    pn[mi] = n0 + g; py_[mi] = y0 + ty; px_[mi] = x0 + tx;
+    pvalid[mi] = pn[mi] < p.N && py_[mi] < p.Ho && px_[mi] < p.Wo;
+  }
+  if (p.out_mode == OUT_NHWC) {
+    using RV = typename std::conditional<E::DTYPE == 0, u32x4, u32x2>::type;   // 4 output channels
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.out), 0, p.rbytes, 0x00020000);
+    uint32_t ovo[MI], rvo[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const uint32_t opix = (uint32_t)((pn[mi] * p.Ho + py_[mi]) * p.Wo + px_[mi]);
+      const bool ok = pvalid[mi] && co_w < p.Cout;
+      ovo[mi] = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_w) * ESZ : p.obytes;
+      uint32_t rpix = opix;
+      if (p.res_mode == RES_UP2) rpix = (uint32_t)((pn[mi] * p.Hr + (py_[mi] >> 1)) * p.Wr + (px_[mi] >> 1));
+      rvo[mi] = (ok && p.res_mode != RES_NONE) ? (rpix * (uint32_t)p.Cout + (uint32_t)co_w) * ESZ : p.rbytes;
+    }
+    RV rr[MI][NI];
+    if (p.res_mode != RES_NONE) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if constexpr (E::DTYPE == 0) rr[mi][ni] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, rvo[mi] + ni * 16 * ESZ, 0, 0));
+          else rr[mi][ni] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsr, rvo[mi] + ni * 16 * ESZ, 0, 0));
+        }
+    }
+    f32x4 add4[MULTI ? MI : 1][NI];   // bias + emb per (image, channel quad)
+#pragma unroll
+    for (int k = 0; k < (MULTI ? MI : 1); ++k)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int co = co_w + ni * 16;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (co < p.Cout) {
+          if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + co);
+          if (p.emb) {
+            const int n = MULTI ? min(pn[k], p.N - 1) : n0;
+            const f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)n * p.emb_stride + co);
+            v = f32x4{v[0] + ev[0], v[1] + ev[1], v[2] + ev[2], v[3] + ev[3]};
+          }
+        }
+        add4[k][ni] = v;
+      }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         if (co_w + ni * 16 >= p.Cout) continue;
+        const f32x4 ad = add4[MULTI ? mi : 0][ni];
         float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = acc[mi][ni][j] + bias4[ni][j];
-        if (erow) {
-          const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + ni * 16);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += ev[j];
-        }
+        for (int j = 0; j < 4; ++j) o[j] = acc[mi][ni][j] + ad[j];
         if (p.res_mode != RES_NONE) {
-          auto ld4 = [&](const T* q, float (&d)[4]) {
-            if constexpr (E::DTYPE == 0) {
-              f32x4 t = *reinterpret_cast<const f32x4*>(q);
-              d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3];
-            } else {
-              bf16x4 t = *reinterpret_cast<const bf16x4*>(q);
-              d[0] = (float)t[0]; d[1] = (float)t[1]; d[2] = (float)t[2]; d[3] = (float)t[3];
-            }
-          };
-          float rv[4];
-          if (p.res_mode != RES_POOL2) {
-            ld4(rrow + ni * 16, rv);
+          if constexpr (E::DTYPE == 0) {
+            const f32x4 t = __builtin_bit_cast(f32x4, rr[mi][ni]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += t[j];
           } else {
-            float r0[4], r1[4], r2[4], r3[4];
-            const T* q = rrow + ni * 16;
-            ld4(q, r0); ld4(q + p.Cout, r1); ld4(q + (size_t)p.Wr * p.Cout, r2); ld4(q + (size_t)(p.Wr + 1) * p.Cout, r3);
+            const bf16x4 t = __builtin_bit_cast(bf16x4, rr[mi][ni]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rv[j] = 0.25f * ((r0[j] + r1[j]) + (r2[j] + r3[j]));
+            for (int j = 0; j < 4; ++j) o[j] += (float)t[j];
           }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += rv[j];
         }
-#ifdef CONV_STAMPS
-        if (p.ablate & 1) { if (o[0] == 12345.678f) orow[0] = (T)o[1]; continue; }
-#endif
         if constexpr (E::DTYPE == 0) {
-          *reinterpret_cast<f32x4*>(orow + ni * 16) = f32x4{o[0], o[1], o[2], o[3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{o[0], o[1], o[2], o[3]}), rso, ovo[mi] + ni * 16 * ESZ, 0, 0);
         } else {
           bf16x4 t;
 #pragma unroll
           for (int j = 0; j < 4; ++j) t[j] = (bf16)o[j];
-          *reinterpret_cast<bf16x4*>(orow + ni * 16) = t;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t), rso, ovo[mi] + ni * 16 * ESZ, 0, 0);
         }
       }
-    } else {  // OUT_NCHW_F32 (network output): lanes lr are 16 consecutive pixels of a row -> 64-byte fp32 segments
+  } else {  // OUT_NCHW_F32 (network output): lanes lr are 16 consecutive pixels of a row -> 64-byte fp32 segments
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      if (!pvalid[mi]) continue;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = co_w + ni * 16 + r;
           if (c < p.Cout)
-            reinterpret_cast<float*>(p.out)[(((size_t)n * p.Cout + c) * p.Ho + y) * p.Wo + x] = acc[mi][ni][r] + (p.bias ? p.bias[c] : 0.f);
+            reinterpret_cast<float*>(p.out)[(((size_t)pn[mi] * p.Cout + c) * p.Ho + py_[mi]) * p.Wo + px_[mi]] = acc[mi][ni][r] + (p.bias ? p.bias[c] : 0.f);
         }
     }
   }
@@ -627,7 +624,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   MI355_REQUIRE(d.C0 % CH == 0 && d.C1 % CH == 0 && Cin > 0, -2, "conv: source channels must be multiples of the 64-byte chunk");
   MI355_REQUIRE(d.mode == CONV_UNIT || d.ks == 3, -1, "conv: resampling modes need a 3x3 kernel");
   MI355_REQUIRE(d.out_mode == OUT_NCHW_F32 || d.Cout % 4 == 0, -2, "conv: NHWC output needs Cout % 4 == 0");
-  MI355_REQUIRE(d.mode != CONV_POOL2 || (d.Hs % 2 == 0 && d.Ws % 2 == 0), -2, "conv: avg-pool gather needs even size");
+  MI355_REQUIRE(d.mode != CONV_POOL2 && d.res_mode != RES_POOL2, -4, "conv: average pooling is a separate pass (affine_pool / resample), not a gather mode");
   Geo g; compute_geo(d, g);
   MI355_REQUIRE(g.lds <= 160 * 1024, -4, "conv: LDS budget exceeded");
   MI355_REQUIRE(g.pit <= g.pit_t, -4, "conv: input patch too large for the staging loops");
@@ -643,13 +640,16 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   MI355_REQUIRE(b0 < 0xFFFF0000ull && b1 < 0xFFFF0000ull && wb < 0xFFFF0000ull, -4,
                 "conv: a source tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb;
+  a.Hr = d.res_mode == RES_UP2 ? g.Ho / 2 : g.Ho;
+  a.Wr = d.res_mode == RES_UP2 ? g.Wo / 2 : g.Wo;
+  const size_t ob = (size_t)d.N * g.Ho * g.Wo * d.Cout * esz, rb = (size_t)d.N * a.Hr * a.Wr * d.Cout * esz;
+  MI355_REQUIRE(ob < 0xFFFF0000ull && rb < 0xFFFF0000ull, -4, "conv: output tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
+  a.obytes = (uint32_t)ob; a.rbytes = d.res ? (uint32_t)rb : 0u;
   a.dbg = reinterpret_cast<unsigned long long*>(d.dbg);
   { static const int stg = getenv("MI355_CONV_STAGGER") ? atoi(getenv("MI355_CONV_STAGGER")) : 0; a.stagger = stg; }
   { static const int abl = getenv("MI355_CONV_ABLATE") ? atoi(getenv("MI355_CONV_ABLATE")) : 0; a.ablate = abl; }
   a.emb = d.emb; a.emb_stride = d.emb_stride;
   a.res = d.res; a.res_mode = d.res ? d.res_mode : RES_NONE;
-  a.Hr = d.res_mode == RES_UP2 ? g.Ho / 2 : (d.res_mode == RES_POOL2 ? g.Ho * 2 : g.Ho);
-  a.Wr = d.res_mode == RES_UP2 ? g.Wo / 2 : (d.res_mode == RES_POOL2 ? g.Wo * 2 : g.Wo);
   a.out = d.out; a.out_mode = d.out_mode;
   a.lvw = g.lvw; a.lth = g.lth; a.G = g.G; a.PW = g.PW; a.PH = g.PH; a.NP = g.NP;
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;

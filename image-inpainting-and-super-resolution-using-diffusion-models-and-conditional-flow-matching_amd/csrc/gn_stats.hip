@@ -122,7 +122,54 @@ __global__ void __launch_bounds__(256) groupnorm_nchw_kernel(const float* x, con
   }
 }
 
+// out[n, y, x, c] = mean over the 2x2 block of  silu?(a[n,c] * in + b[n,c])   (ResBlock(down=True): GN, SiLU, AvgPool2d(2),
+// AD/image_diffusion/unet.py:332-337,236).  HBM-bound, 16-byte fragments; the pooled tensor feeds the conv unchanged.
+template <typename T>
+__global__ void __launch_bounds__(256) affine_pool_kernel(const T* in, const float* a, const float* b, int silu, T* out, int N, int Hs,
+                                                        int Ws, int C) {
+  constexpr int V = Elem<T>::VEC;
+  constexpr bool FAST = Elem<T>::DTYPE == 1;
+  const int Ho = Hs / 2, Wo = Ws / 2, CV = C / V;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)N * Ho * Wo * CV) return;
+  const int f = idx % CV;
+  size_t r = idx / CV;
+  const int x = r % Wo; r /= Wo;
+  const int y = r % Ho;
+  const size_t n = r / Ho;
+  float av[V], bv[V], acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { av[j] = a ? a[n * C + f * V + j] : 1.f; bv[j] = a ? b[n * C + f * V + j] : 0.f; acc[j] = 0.f; }
+  const T* base = in + ((n * Hs + 2 * y) * Ws + 2 * x) * C + f * V;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const T* q = base + ((size_t)(k >> 1) * Ws + (k & 1)) * C;
+    float v[V];
+    frag_to_float(*reinterpret_cast<const u32x4*>(q), v, T());
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float t = av[j] * v[j] + bv[j];
+      acc[j] += silu ? silu_f<FAST>(t) : t;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] *= 0.25f;
+  *reinterpret_cast<u32x4*>(out + (((n * Ho + y) * Wo + x) * C + f * V)) = float_to_frag(acc, T());
+}
+
 }  // namespace
+
+int affine_pool_launch(int dtype, const void* in, const float* a, const float* b, int silu, void* out, int N, int Hs, int Ws, int C,
+                       hipStream_t s) {
+  const int V = dtype == 0 ? 4 : 8;
+  MI355_REQUIRE(C % V == 0 && Hs % 2 == 0 && Ws % 2 == 0, -2, "affine_pool: needs even size and 16-byte channel fragments");
+  const size_t total = (size_t)N * (Hs / 2) * (Ws / 2) * (C / V);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == 0) hipLaunchKernelGGL(affine_pool_kernel<float>, grid, dim3(256), 0, s, (const float*)in, a, b, silu, (float*)out, N, Hs, Ws, C);
+  else hipLaunchKernelGGL(affine_pool_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, a, b, silu, (bf16*)out, N, Hs, Ws, C);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 int gn_affine_launch(const GnDesc& d, hipStream_t stream) {
   const int C = d.C0 + d.C1;

@@ -63,6 +63,9 @@ struct GnDesc {
   float* b = nullptr;
 };
 int gn_affine_launch(const GnDesc& d, hipStream_t stream);
+// out = avgpool2x2(silu?(a * in + b)) on NHWC tensors (a, b per (n, c), may be null): the ResBlock(down=True) input path
+int affine_pool_launch(int dtype, const void* in, const float* a, const float* b, int silu, void* out, int N, int Hs, int Ws, int C,
+                       hipStream_t s);
 
 // ---- attention --------------------------------------------------------------------------------------
 // qkv: NHWC [N][T][3*C] with the reference channel order (legacy: per head [q|k|v]; new: [q heads|k heads|v heads])

@@ -17,7 +17,7 @@ int unet_enumerate_params(const mi355_unet_config& cfg, std::vector<ParamInfo>& 
 
 struct PlanTensor { int C, H, W; bool f32; size_t offset_per_image; };  // element type T unless f32
 
-enum OpKind { OP_GN = 0, OP_CONV = 1, OP_ATTN = 2, OP_RESAMPLE = 3 };
+enum OpKind { OP_GN = 0, OP_CONV = 1, OP_ATTN = 2, OP_RESAMPLE = 3, OP_POOLAFF = 4 };
 
 struct PlanOp {
   int kind;

@@ -124,10 +124,21 @@ struct Walker {
     P(p + ".emb_layers.1.weight", {ew, 4 * cfg.model_channels});
     P(p + ".emb_layers.1.bias", {ew});
     add_gn(s0, s1, p + ".in_layers.0.weight", p + ".in_layers.0.bias", -1);
-    const int mode = up ? CONV_UP2 : (down ? CONV_POOL2 : CONV_UNIT);
-    const int h1 = add_conv(p + ".in_layers.2", s0, s1, cin, cout, 3, mode, false, 1, 1, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC);
+    int h1;
+    int res = s0, res_mode = up ? RES_UP2 : RES_SAME;
+    if (down) {
+      // ResBlock(down=True): h = conv(AvgPool(SiLU(GN(x)))), x -> AvgPool(x) (unet.py:332-337): both pools are small HBM-bound
+      // pre-passes (the first one fused with the GN affine + SiLU), so the conv itself stays a plain stride-1 conv.
+      if (s1 >= 0) { err = "ResBlock(down) over a channel concat is not supported"; return -1; }
+      PlanOp op; op.kind = OP_POOLAFF; op.src0 = s0; op.pro_silu = 1;
+      op.dst = tensor(T(s0).C, T(s0).H / 2, T(s0).W / 2);
+      net->ops.push_back(op);
+      h1 = add_conv(p + ".in_layers.2", op.dst, -1, cin, cout, 3, CONV_UNIT, false, 0, 0, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC);
+      res = resample(s0, CONV_POOL2);
+    } else {
+      h1 = add_conv(p + ".in_layers.2", s0, s1, cin, cout, 3, up ? CONV_UP2 : CONV_UNIT, false, 1, 1, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC);
+    }
     add_gn(h1, -1, p + ".out_layers.0.weight", p + ".out_layers.0.bias", film ? eoff : -1);
-    int res = s0, res_mode = up ? RES_UP2 : (down ? RES_POOL2 : RES_SAME);
     if (cin != cout) {
       if (up || down) { err = "ResBlock(up/down) with a channel change is not supported"; return -1; }
       auto it = pidx.find(p + ".skip_connection.weight");
@@ -453,6 +464,10 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
       r.kind = MI355_OP_ATTN; r.cin = 3 * op.heads * op.ch; r.cout = op.heads * op.ch; r.h = s0.H; r.w = s0.W;
       r.flops = 4.0 * B * (double)a.T * a.T * op.heads * op.ch;
       r.bytes = 4.0 * B * a.T * op.heads * op.ch * esz;
+    } else if (op.kind == OP_POOLAFF) {
+      rc = affine_pool_launch(dtype, TP(op.src0), F(l.gna), F(l.gnb), op.pro_silu, TP(op.dst), B, s0.H, s0.W, s0.C, stream);
+      r.kind = MI355_OP_RESAMPLE; r.cin = s0.C; r.h = s0.H; r.w = s0.W;
+      r.bytes = 1.25 * B * s0.H * s0.W * (double)s0.C * esz;
     } else {
       rc = resample_launch(dtype, TP(op.src0), TP(op.dst), B, s0.H, s0.W, s0.C, op.mode, stream);
       r.kind = MI355_OP_RESAMPLE; r.cin = s0.C; r.h = s0.H; r.w = s0.W;
