@@ -372,30 +372,35 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     pvalid[mi] = pn[mi] < p.N && py_[mi] < p.Ho && px_[mi] < p.Wo;
   }
   if (p.out_mode == OUT_NHWC) {
-    using RV = typename std::conditional<E::DTYPE == 0, u32x4, u32x2>::type;   // 4 output channels
+    // bf16: the natural piece is 8 bytes per lane; two v_permlane16_swap per pair of channel tiles turn it into 16 bytes
+    // (8 consecutive channels) per lane, halving the store / residual-load instruction count (the store tail is
+    // issue-bound).  After swap(X = tile a, Y = tile b): 16-lane row 0 holds tile a ch 0-7, row 1 tile b ch 0-7,
+    // row 2 tile a ch 8-15, row 3 tile b ch 8-15 (probed on gfx950: tools/probe/permlane_probe.cpp); the swap is an involution.
+    constexpr bool PAIR = E::DTYPE == 1;
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.obytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.out), 0, p.rbytes, 0x00020000);
+    const int co_s = PAIR ? nt * BN + wn * WTN + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;   // first channel this lane stores
     uint32_t ovo[MI], rvo[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const uint32_t opix = (uint32_t)((pn[mi] * p.Ho + py_[mi]) * p.Wo + px_[mi]);
-      const bool ok = pvalid[mi] && co_w < p.Cout;
-      ovo[mi] = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_w) * ESZ : p.obytes;
+      const bool ok = pvalid[mi] && co_s < p.Cout;
+      ovo[mi] = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.obytes;
       uint32_t rpix = opix;
       if (p.res_mode == RES_UP2) rpix = (uint32_t)((pn[mi] * p.Hr + (py_[mi] >> 1)) * p.Wr + (px_[mi] >> 1));
-      rvo[mi] = (ok && p.res_mode != RES_NONE) ? (rpix * (uint32_t)p.Cout + (uint32_t)co_w) * ESZ : p.rbytes;
+      rvo[mi] = (ok && p.res_mode != RES_NONE) ? (rpix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.rbytes;
     }
-    RV rr[MI][NI];
+    constexpr int NP2 = PAIR ? NI / 2 : NI;     // 16-byte pieces per pixel row of this wave
+    constexpr int PSTEP = PAIR ? 32 : 16;       // channels between consecutive pieces
+    u32x4 rr[MI][NP2];
     if (p.res_mode != RES_NONE) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          if constexpr (E::DTYPE == 0) rr[mi][ni] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, rvo[mi] + ni * 16 * ESZ, 0, 0));
-          else rr[mi][ni] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsr, rvo[mi] + ni * 16 * ESZ, 0, 0));
-        }
+        for (int k = 0; k < NP2; ++k)
+          rr[mi][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, rvo[mi] + k * PSTEP * ESZ, 0, 0));
     }
-    f32x4 add4[MULTI ? MI : 1][NI];   // bias + emb per (image, channel quad)
+    f32x4 add4[MULTI ? MI : 1][NI];   // bias + emb per (image, channel quad), original (unswapped) layout
 #pragma unroll
     for (int k = 0; k < (MULTI ? MI : 1); ++k)
 #pragma unroll
@@ -413,34 +418,46 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
         add4[k][ni] = v;
       }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi) {
+      if constexpr (!PAIR) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        if (co_w + ni * 16 >= p.Cout) continue;
-        const f32x4 ad = add4[MULTI ? mi : 0][ni];
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = acc[mi][ni][j] + ad[j];
-        if (p.res_mode != RES_NONE) {
-          if constexpr (E::DTYPE == 0) {
+        for (int ni = 0; ni < NI; ++ni) {
+          const f32x4 ad = add4[MULTI ? mi : 0][ni];
+          f32x4 o = f32x4{acc[mi][ni][0] + ad[0], acc[mi][ni][1] + ad[1], acc[mi][ni][2] + ad[2], acc[mi][ni][3] + ad[3]};
+          if (p.res_mode != RES_NONE) {
             const f32x4 t = __builtin_bit_cast(f32x4, rr[mi][ni]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += t[j];
-          } else {
-            const bf16x4 t = __builtin_bit_cast(bf16x4, rr[mi][ni]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += (float)t[j];
+            o = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]};
           }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo[mi] + ni * 16 * ESZ, 0, 0);
         }
-        if constexpr (E::DTYPE == 0) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{o[0], o[1], o[2], o[3]}), rso, ovo[mi] + ni * 16 * ESZ, 0, 0);
-        } else {
-          bf16x4 t;
+      } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = (bf16)o[j];
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t), rso, ovo[mi] + ni * 16 * ESZ, 0, 0);
+        for (int k = 0; k < NP2; ++k) {
+          float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.res_mode != RES_NONE) {   // un-swap the 8-channel residual piece back to the accumulator layout
+            const auto s0 = __builtin_amdgcn_permlane16_swap(rr[mi][k][0], rr[mi][k][2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(rr[mi][k][1], rr[mi][k][3], false, false);
+            const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              ra[2 * j] = __builtin_bit_cast(float, xa[j] << 16); ra[2 * j + 1] = __builtin_bit_cast(float, xa[j] & 0xffff0000u);
+              rb[2 * j] = __builtin_bit_cast(float, xb[j] << 16); rb[2 * j + 1] = __builtin_bit_cast(float, xb[j] & 0xffff0000u);
+            }
+          }
+          const f32x4 ada = add4[MULTI ? mi : 0][2 * k], adb = add4[MULTI ? mi : 0][2 * k + 1];
+          bf16x4 ta, tb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ta[j] = (bf16)(acc[mi][2 * k][j] + ada[j] + ra[j]);
+            tb[j] = (bf16)(acc[mi][2 * k + 1][j] + adb[j] + rb[j]);
+          }
+          const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+          const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
+          const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo[mi] + k * PSTEP * ESZ, 0, 0);
         }
       }
+    }
   } else {  // OUT_NCHW_F32 (network output): lanes lr are 16 consecutive pixels of a row -> 64-byte fp32 segments
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
