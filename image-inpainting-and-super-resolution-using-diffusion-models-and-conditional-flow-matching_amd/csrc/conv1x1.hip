@@ -21,7 +21,7 @@ struct K1Args {
   const void* res;
   void* out;
   int lvw, lth, G, tiles_x, tiles_y, ntn;
-  uint32_t bytes0, bytes1, wbytes;
+  uint32_t bytes0, bytes1, wbytes, obytes;
 };
 
 template <bool FAST> __device__ __forceinline__ float silu1(float v) {
@@ -55,6 +55,8 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src1 ? p.src1 : p.src0), 0, p.bytes1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.obytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.out), 0, p.obytes, 0x00020000);
 
   // ---- stage the activation tile, all chunks ----
   const int fq = tid & 3, frow = tid >> 2;
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
   prefetch_w(0);
 
   // output pixel bookkeeping for the epilogue
-  size_t opix[MI]; int on[MI]; bool ovalid[MI];
+  uint32_t opix[MI]; int on[MI]; bool ovalid[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = wm * WTM + mi * 16 + lr;
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
     const int n = n0 + g, y = y0 + ty, x = x0 + tx;
     ovalid[mi] = n < p.N && y < p.H && x < p.W;
     on[mi] = n;
-    opix[mi] = ((size_t)n * p.H + y) * p.W + x;
+    opix[mi] = (uint32_t)((n * p.H + y) * p.W + x);
   }
 
   int gi = 0;
@@ -177,44 +179,68 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
         }
       }
     }
-    // ---- epilogue of this output-channel tile ----
-    const int co_w = (nt0 + nti) * BN + wn * WTN + 4 * lq;
+    // ---- epilogue of this output-channel tile: loads first, then 16-byte stores (bf16: tile pairs via permlane16_swap) ----
+    {
+      constexpr bool PAIR = E::DTYPE == 1;
+      const int co_t = (nt0 + nti) * BN + wn * WTN;
+      const int co_w = co_t + 4 * lq;
+      const int co_s = PAIR ? co_t + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;
+      constexpr int NP2 = PAIR ? NI / 2 : NI, PSTEP = PAIR ? 32 : 16;
+      u32x4 rr[MI][NP2];
+      if (p.res) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int co = co_w + ni * 16;
-      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int k = 0; k < NP2; ++k)
+            rr[mi][k] = bload16(rsr, ovalid[mi] ? (opix[mi] * (uint32_t)p.Cout + co_s + k * PSTEP) * ESZ : p.obytes, 0);
+      }
+      f32x4 bias4[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bias4[ni] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co_w + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        if (!ovalid[mi]) continue;
-        float o[4];
+        f32x4 ad[NI];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = acc[mi][ni][j] + bv[j];
-        if (p.emb) {
-          const f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)on[mi] * p.emb_stride + co);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += ev[j];
-        }
-        if (p.res) {
-          const T* q = reinterpret_cast<const T*>(p.res) + opix[mi] * p.Cout + co;
-          if constexpr (E::DTYPE == 0) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += t[j];
-          } else {
-            const bf16x4 t = *reinterpret_cast<const bf16x4*>(q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += (float)t[j];
+        for (int ni = 0; ni < NI; ++ni) {
+          ad[ni] = bias4[ni];
+          if (p.emb) {
+            const f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)min(on[mi], p.N - 1) * p.emb_stride + co_w + ni * 16);
+            ad[ni] = f32x4{ad[ni][0] + ev[0], ad[ni][1] + ev[1], ad[ni][2] + ev[2], ad[ni][3] + ev[3]};
           }
         }
-        T* op = reinterpret_cast<T*>(p.out) + opix[mi] * p.Cout + co;
-        if constexpr (E::DTYPE == 0) {
-          *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
-        } else {
-          bf16x4 t;
+        const uint32_t obase = ovalid[mi] ? (opix[mi] * (uint32_t)p.Cout + co_s) * ESZ : p.obytes;
+        if constexpr (!PAIR) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = (bf16)o[j];
-          *reinterpret_cast<bf16x4*>(op) = t;
+          for (int ni = 0; ni < NI; ++ni) {
+            f32x4 o = f32x4{acc[mi][ni][0] + ad[ni][0], acc[mi][ni][1] + ad[ni][1], acc[mi][ni][2] + ad[ni][2], acc[mi][ni][3] + ad[ni][3]};
+            if (p.res) { const f32x4 t = __builtin_bit_cast(f32x4, rr[mi][ni]); o = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]}; }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, obase + ni * 16 * ESZ, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NP2; ++k) {
+            float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.res) {
+              const auto s0 = __builtin_amdgcn_permlane16_swap(rr[mi][k][0], rr[mi][k][2], false, false);
+              const auto s1 = __builtin_amdgcn_permlane16_swap(rr[mi][k][1], rr[mi][k][3], false, false);
+              const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                ra[2 * j] = __builtin_bit_cast(float, xa[j] << 16); ra[2 * j + 1] = __builtin_bit_cast(float, xa[j] & 0xffff0000u);
+                rb[2 * j] = __builtin_bit_cast(float, xb[j] << 16); rb[2 * j + 1] = __builtin_bit_cast(float, xb[j] & 0xffff0000u);
+              }
+            }
+            bf16x4 ta, tb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              ta[j] = (bf16)(acc[mi][2 * k][j] + ad[2 * k][j] + ra[j]);
+              tb[j] = (bf16)(acc[mi][2 * k + 1][j] + ad[2 * k + 1][j] + rb[j]);
+            }
+            const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+            const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
+            const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, obase + k * PSTEP * ESZ, 0, 0);
+          }
         }
       }
     }
@@ -278,6 +304,9 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream) {
   MI355_REQUIRE(b0 < 0xFFFF0000ull && b1 < 0xFFFF0000ull && wb < 0xFFFF0000ull, -4,
                 "conv1x1: a source tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb;
+  const size_t ob = (size_t)d.N * d.Hs * d.Ws * d.Cout * esz;
+  MI355_REQUIRE(ob < 0xFFFF0000ull, -4, "conv1x1: output tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
+  a.obytes = (uint32_t)ob;
   dim3 grid(mt, (ntiles + ntn - 1) / ntn);
   const size_t lds = (size_t)nchunks * BM * 64 + wl;
   if (d.dtype == 0) { if (BM == 128) launch1<float, 128>(a, grid, lds, stream); else launch1<float, 64>(a, grid, lds, stream); }
