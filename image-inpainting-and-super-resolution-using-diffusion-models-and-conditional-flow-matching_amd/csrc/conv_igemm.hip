@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
   constexpr int WTILE = BN * 64;             // bytes of one (chunk, tap) weight tile of this workgroup
   constexpr int WIT = (3 * WTILE + NTHREADS * 16 - 1) / (NTHREADS * 16);  // 16-B weight fragments per thread per kernel row
   constexpr int NPL = KS == 1 ? 3 : 1;       // patch planes
+  constexpr int WD = (KS == 3 && BM == 64 && BN <= 64) ? 3 : 1;   // weight prefetch distance in kernel rows (register ring)
   constexpr int PLANE = PIT * FR * PROW;     // bytes per plane (every thread owns PIT fragment slots: no bounds checks)
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
 #endif
 
   u32x4 raw[NPL][PIT];
-  u32x4 wreg[WIT];
+  u32x4 wreg[WD][WIT];
   constexpr int NAB = MULTI ? PIT : 1;   // (a, b) register sets per plane
   float pa[NPL][NAB][V], pb[NPL][NAB][V];
 
@@ -251,15 +252,17 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     }
   };
   // weight tiles of one kernel row: three consecutive (chunk, tap) tiles starting at linear tile index t0
-  auto prefetch_w = [&](int t0) {
+  auto prefetch_w = [&](int t0, auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
 #ifdef CONV_STAMPS
     if (p.ablate & 8) return;
 #endif
     const uint32_t so = wbase + (uint32_t)t0 * wtile_pack;
 #pragma unroll
-    for (int i = 0; i < WIT; ++i) wreg[i] = buf_load16(rsw, woff[i], so);
+    for (int i = 0; i < WIT; ++i) wreg[slot][i] = buf_load16(rsw, woff[i], so);
   };
-  auto commit_w = [&](int buf) {
+  auto commit_w = [&](int buf, auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
 #ifdef CONV_STAMPS
     if (p.ablate & 8) return;
 #endif
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
 #pragma unroll
     for (int i = 0; i < WIT; ++i)
       if ((i + 1) * NTHREADS * 16 <= 3 * WTILE || (i * NTHREADS + tid) * 16 < 3 * WTILE)
-        *reinterpret_cast<u32x4*>(dst + i * NTHREADS * 16) = wreg[i];
+        *reinterpret_cast<u32x4*>(dst + i * NTHREADS * 16) = wreg[slot][i];
   };
   auto mma_tap = [&](const char* pa_, const int (&ao)[MI], int aimm, const char* wt, const int (&bo)[NI]) {
     u32x4 a[MI], b[NI];
@@ -302,7 +305,8 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) { a1[mi] = arow[mi] + p.PW * PROW; a2[mi] = arow[mi] + 2 * p.PW * PROW; }
     prefetch_patch(0, IC<0>());
-    prefetch_w(0);
+    prefetch_w(0, IC<0>());
+    if constexpr (WD == 3) { prefetch_w(3, IC<1>()); prefetch_w(6, IC<2>()); }
     STAMP(0)
     for (int c = 0; c < p.nchunks; ++c) {
       if (c > 0) __syncthreads();           // every wave has finished reading the previous chunk's patch
@@ -311,14 +315,15 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
       STAMP(1)
       if (c + 1 < p.nchunks) prefetch_patch(c + 1, IC<0>());
       STAMP(5)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky, ++gi) {
-        commit_w(gi & 1);
+      auto row = [&](auto kyc) {
+        constexpr int ky = decltype(kyc)::value;
+        constexpr int slot = WD == 3 ? ky : 0;
+        commit_w(gi & 1, IC<slot>());
         STAMP(3)
         __syncthreads();                    // patch + this row's weights visible; also orders weight-buffer reuse
         STAMP(4)
-        const int nxt = c * 9 + (ky + 1) * 3;
-        if (nxt < p.nchunks * 9) prefetch_w(nxt);
+        const int nxt = WD == 3 ? (c + 1) * 9 + ky * 3 : c * 9 + (ky + 1) * 3;
+        if (nxt < p.nchunks * 9) prefetch_w(nxt, IC<slot>());
         STAMP(5)
         const char* wt = wlds + (gi & 1) * (3 * WTILE);
 #pragma unroll
@@ -328,7 +333,9 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
           else mma_tap(patch, a2, kx * PROW, wt + kx * WTILE, brow);
         }
         STAMP(6)
-      }
+        ++gi;
+      };
+      row(IC<0>()); row(IC<1>()); row(IC<2>());
     }
   } else {
     const int ngroups = (p.nchunks + 2) / 3;
@@ -338,7 +345,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
       prefetch_patch(3 * g, IC<0>());
       if (nn > 1) prefetch_patch(3 * g + 1, IC<1>());
       if (nn > 2) prefetch_patch(3 * g + 2, IC<2>());
-      prefetch_w(3 * g);
+      prefetch_w(3 * g, IC<0>());
     };
     prefetch_group(0);
     for (int g = 0; g < ngroups; ++g, ++gi) {
@@ -347,7 +354,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
       commit_patch(3 * g, IC<0>());
       if (nc > 1) commit_patch(3 * g + 1, IC<1>());
       if (nc > 2) commit_patch(3 * g + 2, IC<2>());
-      commit_w(gi & 1);
+      commit_w(gi & 1, IC<0>());
       __syncthreads();
       if (g + 1 < ngroups) prefetch_group(g + 1);
       const char* wt = wlds + (gi & 1) * (3 * WTILE);
@@ -542,10 +549,11 @@ int compute_geo(const ConvDesc& d, Geo& g) {
   if (Q != P) { cand[nc][0] = 64; cand[nc++][1] = Q; }
   int bestBM = cand[nc - 1][0], bestBN = cand[nc - 1][1];
   const long img_slots = (long)(1 << ilog2_ceil(g.Wo)) * (1 << ilog2_ceil(g.Ho));
+  static const long min_wgs = getenv("MI355_CONV_MINWG") ? atol(getenv("MI355_CONV_MINWG")) : 512;
   for (int i = 0; i < nc; ++i) {
     if (cand[i][0] == 128 && img_slots < 128) continue;   // several images per tile: only the 64-pixel tile has that variant
     const long wgs = ((M + cand[i][0] - 1) / cand[i][0]) * ((d.Cout + cand[i][1] - 1) / cand[i][1]);
-    if (wgs >= 512) { bestBM = cand[i][0]; bestBN = cand[i][1]; break; }
+    if (wgs >= min_wgs) { bestBM = cand[i][0]; bestBN = cand[i][1]; break; }
   }
   g.BM = bestBM; g.BN = bestBN;
   const int lw = ilog2_ceil(g.Wo);
