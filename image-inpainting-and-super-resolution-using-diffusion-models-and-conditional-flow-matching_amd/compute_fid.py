@@ -33,9 +33,9 @@ def load_checkpoint(net, path):
     return net
 
 
-def make_gen_1_img(new_net, batch_size_fid=1024, integration_steps=100, integration_method="euler", device="cuda:0"):
-    if integration_method != "euler":
-        raise NotImplementedError("only --integration_method euler is built (dopri5 is a 'next' row, SURVEY.md 8f)")
+def make_gen_1_img(new_net, batch_size_fid=1024, integration_steps=100, integration_method="euler", device="cuda:0", tol=1e-5):
+    if integration_method not in ("euler", "dopri5"):
+        raise NotImplementedError("--integration_method must be euler or dopri5")
     device = torch.device(device)
 
     def gen_1_img(unused_latent):
@@ -43,8 +43,15 @@ def make_gen_1_img(new_net, batch_size_fid=1024, integration_steps=100, integrat
             B = int(batch_size_fid)
             lo, hi = mdist.shard_range(B)
             x = torch.randn(B, 3, 32, 32, device=device)[lo:hi].contiguous()  # same draw on every rank, rank takes its slice
-            t_span = torch.linspace(0, 1, integration_steps + 1).tolist()
-            _, _, img = new_net.engine(device).cfm_euler(x, t_span, want_u8=True)  # (traj*127.5+128).clip(0,255).to(uint8)
+            if integration_method == "euler":
+                t_span = torch.linspace(0, 1, integration_steps + 1).tolist()
+                _, _, img = new_net.engine(device).cfm_euler(x, t_span, want_u8=True)  # (traj*127.5+128).clip(0,255).to(uint8)
+            else:  # odeint(new_net, x, linspace(0,1,2), rtol=tol, atol=tol, method="dopri5")  (cifar10/compute_fid.py:80-85)
+                from mi355.ode import odeint_dopri5
+                from mi355.ops import default_ops
+
+                traj, _ = odeint_dopri5(lambda t, y: new_net(torch.tensor(float(t), device=device), y), x, 0.0, 1.0, tol, tol)
+                img = default_ops.quantize_u8(traj.contiguous())
             return mdist.all_gather_batch(img, B)
 
     return gen_1_img
@@ -56,7 +63,8 @@ def main(argv=None):
     ap.add_argument("--input_dir", default="./results")
     ap.add_argument("--model", default="otcfm")
     ap.add_argument("--integration_steps", type=int, default=100)
-    ap.add_argument("--integration_method", default="euler")
+    ap.add_argument("--integration_method", default="dopri5")
+    ap.add_argument("--tol", type=float, default=1e-5)
     ap.add_argument("--step", type=int, default=400000)
     ap.add_argument("--num_gen", type=int, default=50000)
     ap.add_argument("--batch_size_fid", type=int, default=1024)
@@ -67,7 +75,7 @@ def main(argv=None):
     path = f"{a.input_dir}/{a.model}/{a.model}_cifar10_weights_step_{a.step}.pt"
     print("path: ", path)
     load_checkpoint(net, path)
-    gen = make_gen_1_img(net, a.batch_size_fid, a.integration_steps, a.integration_method, device)
+    gen = make_gen_1_img(net, a.batch_size_fid, a.integration_steps, a.integration_method, device, a.tol)
     try:
         from cleanfid import fid
     except ImportError as e:

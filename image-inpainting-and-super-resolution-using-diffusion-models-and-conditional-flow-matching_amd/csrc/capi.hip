@@ -236,6 +236,22 @@ int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream) { r
 int mi355_to_unit_range(const float* x, float* out, int64_t n, void* stream) { return to_unit_range_launch(x, out, n, S(stream)); }
 int mi355_randn(float* out, uint64_t seed, uint64_t offset, int64_t n, void* stream) { return randn_launch(out, seed, offset, n, S(stream)); }
 
+int mi355_rk_combine(float* out, const float* y0, const float* k0, const float* k1, const float* k2, const float* k3, const float* k4,
+                     const float* k5, const float* k6, const float* coeff_host, int nk, int64_t n, void* stream) {
+  MI355_REQUIRE(coeff_host || nk == 0, -1, "rk_combine: null coefficients");
+  const float* k[7] = {k0, k1, k2, k3, k4, k5, k6};
+  return rk_combine_launch(out, y0, k, coeff_host, nk, n, S(stream));
+}
+int mi355_rk_sqnorm(const float* a, const float* sub, const float* b, const float* b2, float atol, float rtol, int64_t n, double* out,
+                    void* stream) {
+  return rk_sqnorm_launch(a, sub, b, b2, atol, rtol, n, out, S(stream));
+}
+int mi355_rk_interp(float* out, const float* y0, const float* y1, const float* y_mid, const float* f0, const float* f1, float dt, float x,
+                    int64_t n, void* stream) {
+  MI355_REQUIRE(out && y0 && y1 && y_mid && f0 && f1, -1, "rk_interp: null argument");
+  return rk_interp_launch(out, y0, y1, y_mid, f0, f1, dt, x, n, S(stream));
+}
+
 int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw) {
   const size_t c = (size_t)max_channels + 32;
   return (int64_t)(2 * al256((size_t)batch * hw * 4 * c * 4) + al256(c * c * 9 * 4 * 2) + 4 * al256((size_t)batch * c * 4) + (1 << 20));

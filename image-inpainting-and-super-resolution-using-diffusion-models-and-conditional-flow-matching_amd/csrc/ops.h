@@ -110,3 +110,10 @@ int randn_launch(float* out, uint64_t seed, uint64_t offset, int64_t n, hipStrea
 int fill_launch(float* x, float v, int64_t n, hipStream_t s);
 int groupnorm_nchw_launch(const float* x, const float* gamma, const float* beta, float* y, int N, int C, int HW, int groups,
                           float eps, int silu, hipStream_t s);
+
+// adaptive RK45 helpers (ode.hip)
+int rk_combine_launch(float* out, const float* y0, const float* const* k, const float* c, int nk, int64_t n, hipStream_t s);
+int rk_sqnorm_launch(const float* a, const float* sub, const float* b, const float* b2, float atol, float rtol, int64_t n, double* out,
+                     hipStream_t s);
+int rk_interp_launch(float* out, const float* y0, const float* y1, const float* ym, const float* f0, const float* f1, float dt, float x,
+                     int64_t n, hipStream_t s);

@@ -88,6 +88,9 @@ SIGNATURES = {
     "mi355_quantize_u8": (_I, [_VP, _VP, _I64, _VP]),
     "mi355_to_unit_range": (_I, [_VP, _VP, _I64, _VP]),
     "mi355_randn": (_I, [_VP, _U64, _U64, _I64, _VP]),
+    "mi355_rk_combine": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _FP, _I, _I64, _VP]),
+    "mi355_rk_sqnorm": (_I, [_VP, _VP, _VP, _VP, _F, _F, _I64, _VP, _VP]),
+    "mi355_rk_interp": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _I64, _VP]),
     "mi355_op_workspace_bytes": (_I64, [_I, _I, _I]),
     "mi355_conv2d": (_I, [_VP, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _I64, _VP]),
     "mi355_qkv_attention": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I64, _VP]),

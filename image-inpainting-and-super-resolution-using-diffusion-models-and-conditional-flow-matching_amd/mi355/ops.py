@@ -106,6 +106,28 @@ class Ops:
         check(_lib.lib().mi355_randn(_req(out, "out"), int(seed), int(offset), out.numel(), _stream()))
         return out
 
+    # --- adaptive RK45 building blocks (csrc/ode.hip) ---
+    def rk_combine(self, out, y0, ks, coeffs):
+        """out = y0 + sum_j coeffs[j] * ks[j]  (y0 may be None; coeffs already include dt)."""
+        assert len(ks) == len(coeffs) <= 7
+        arr = (C.c_float * 7)(*([float(c) for c in coeffs] + [0.0] * (7 - len(coeffs))))
+        kp = [_req(k, "k") for k in ks] + [None] * (7 - len(ks))
+        check(_lib.lib().mi355_rk_combine(_req(out, "out"), _req(y0, "y0") if y0 is not None else None, *kp, arr, len(ks), out.numel(),
+                                          _stream()))
+        return out
+
+    def rk_sqnorm(self, acc, a, sub=None, b=None, b2=None, atol=1.0, rtol=0.0):
+        """acc (device fp64 scalar tensor) += sum(((a - sub) / (atol + rtol * max(|b|, |b2|)))**2)."""
+        check(_lib.lib().mi355_rk_sqnorm(_req(a, "a"), _req(sub, "sub") if sub is not None else None, _req(b, "b") if b is not None else None,
+                                         _req(b2, "b2") if b2 is not None else None, float(atol), float(rtol), a.numel(),
+                                         _req(acc, "acc", torch.float64), _stream()))
+        return acc
+
+    def rk_interp(self, out, y0, y1, ymid, f0, f1, dt, x):
+        check(_lib.lib().mi355_rk_interp(_req(out, "out"), _req(y0, "y0"), _req(y1, "y1"), _req(ymid, "ymid"), _req(f0, "f0"), _req(f1, "f1"),
+                                         float(dt), float(x), out.numel(), _stream()))
+        return out
+
     # --- parity-test ops on NCHW fp32 tensors (pack -> MFMA kernel -> unpack) ---
     def conv2d(self, x, weight, bias=None, stride=1, resample=0, gn=None, gn_silu=False, dtype=_lib.MI355_F32):
         """weight/bias: CPU fp32 tensors in the reference layout [Co,Ci,k,k]; gn = (gamma, beta) device tensors."""

@@ -98,19 +98,33 @@ class NeuralODE:
     step by step from the host with the HIP Euler-update kernel."""
 
     def __init__(self, vector_field, solver="euler", sensitivity="adjoint", atol=1e-4, rtol=1e-4, **kwargs):
-        if solver != "euler":
-            raise NotImplementedError(
-                f"solver={solver!r}: only the fixed-step Euler path is built (adaptive dopri5 is a 'next' row, SURVEY.md 8f)")
+        if solver not in ("euler", "dopri5"):
+            raise NotImplementedError(f"solver={solver!r}: only 'euler' and 'dopri5' are built")
         self.vf = vector_field
         self.solver = solver
+        self.atol, self.rtol = atol, rtol
 
     def to(self, *a, **k):
         return self
+
+    def _call(self, t, x):
+        tt = torch.tensor(float(t), device=x.device, dtype=torch.float32)
+        try:
+            return self.vf(tt, x)
+        except TypeError:
+            return self.vf(tt, x, None)  # torchdyn passes `args` to 3-argument vector fields (mnist/utils_mnist2.py:120)
 
     @torch.no_grad()
     def trajectory(self, x, t_span):
         ts = [float(v) for v in torch.as_tensor(t_span).detach().cpu().tolist()]
         x = x.detach().clone().float().contiguous()
+        if self.solver == "dopri5":
+            # torchdyn's adaptive path (mnist/utils_mnist.py:63-68): states at every requested time; callers index [-1]
+            from mi355.ode import Dopri5
+
+            solver = Dopri5(lambda t, y: [self._call(t, y[0])], self.rtol, self.atol)
+            states = solver.integrate_times([x], ts)   # one continuous adaptive solve, dense output at every requested time
+            return torch.stack([x] + [s[0] for s in states])
         if type(self.vf) is UNetModelWrapper and x.is_cuda:
             _, traj, _ = self.vf.engine(x.device).cfm_euler(x, ts, keep_traj=True)
             return traj

@@ -4,9 +4,9 @@ Kept: get_random_patch / _sample / sample (utils_mnist.py:16-41), downsample_ima
 generate_samples (utils_mnist.py:45-73), generate_samples_eval in its Euler form (utils_mnist2.py:118-138, the
 active definition there: 999 Euler steps over linspace(0,1,1000), state = channel-concat [x, con]) for in-painting
 (`con=`) and its super-resolution sibling (`low_res=`, utils_mnist_hy.py:76-98), ema, infiniteloop.
-The reference's dopri5 variants (utils_mnist.py:90-134, utils_mnist_hy*.py) call the adaptive torchdiffeq
-solver: that is a 'next' row; here `solver="dopri5"` raises NotImplementedError and the same
-functions accept `solver="euler", steps=N`.
+The reference's dopri5 variants (utils_mnist.py:90-134, utils_mnist_hy*.py) run on mi355.ode.Dopri5 (the torchdiffeq
+algorithm restated, HIP kernels for stage combination / error norm / dense output), including the tuple-state quirk;
+`solver="euler", steps=N` selects the fixed-step form.
 """
 import torch
 import torch.nn.functional as F
@@ -48,15 +48,15 @@ def downsample_images(images, target_size):
 
 
 def _check_solver(solver):
-    if solver != "euler":
-        raise NotImplementedError(f"solver={solver!r}: the adaptive dopri5 path is a 'next' row (SURVEY.md 8f); use solver='euler'")
+    if solver not in ("euler", "dopri5"):
+        raise NotImplementedError(f"solver={solver!r}: only 'euler' and 'dopri5' are built")
 
 
-def generate_samples(model, parallel, savedir, step, net_="normal", solver="euler", steps=99, image_shape=(1, 28, 28)):
-    """utils_mnist.py:45-73 (the reference integrates with dopri5 over linspace(0,1,100); Euler over the same span here)."""
+def generate_samples(model, parallel, savedir, step, net_="normal", solver="dopri5", steps=99, image_shape=(1, 28, 28)):
+    """utils_mnist.py:45-73: NeuralODE(model, solver="dopri5", atol=1e-4, rtol=1e-4) over linspace(0, 1, 100), 64 samples."""
     _check_solver(solver)
     model.eval()
-    node_ = NeuralODE(model, solver="euler", sensitivity="adjoint", atol=1e-4, rtol=1e-4)
+    node_ = NeuralODE(model, solver=solver, sensitivity="adjoint", atol=1e-4, rtol=1e-4)
     with torch.no_grad():
         traj = node_.trajectory(torch.randn(64, *image_shape, device=device), t_span=torch.linspace(0, 1, steps + 1, device=device))
         traj = default_ops.to_unit_range(traj[-1, :].view([-1, *image_shape]).contiguous())
@@ -94,20 +94,38 @@ def _euler_conditional(model, x_0, cond, steps):
     return x, steps
 
 
-def generate_samples_eval(model, test_images, savedir=None, batch_size=8, step=0, net_="normal", solver="euler", steps=999):
-    """In-painting evaluation sampler (utils_mnist2.py:118-138): returns (traj, con, nfe)."""
+def _dopri5_conditional(model, x_0, cond, kw):
+    """torchdiffeq.odeint over the TUPLE state (x, cond) with ode_func = (model.forward(x, t, <kw>=cond), cond), atol = rtol =
+    1e-4 (utils_mnist.py:95-108, utils_mnist_hy.py:79-92).  Reference quirk, reproduced: the second component's derivative is
+    the condition itself, so the condition the model sees drifts like e^t along the solve, and it takes part in the error norm."""
+    from mi355.ode import odeint_dopri5
+
+    def f(t, st):
+        tt = torch.tensor(float(t), device=st[0].device)
+        return (model.forward(st[0], tt, **{kw: st[1]}), st[1])
+
+    (x, _), nfe = odeint_dopri5(f, (x_0.float().contiguous(), cond.float().contiguous()), 0.0, 1.0, 1e-4, 1e-4)
+    return x, nfe
+
+
+def generate_samples_eval(model, test_images, savedir=None, batch_size=8, step=0, net_="normal", solver="dopri5", steps=999):
+    """In-painting evaluation sampler: (traj, con, nfe).  solver="dopri5" is utils_mnist.py:90-134 (tuple state, adaptive);
+    solver="euler" is utils_mnist2.py:118-138 (999 Euler steps)."""
     _check_solver(solver)
     model.eval()
     with torch.no_grad():
         con = sample(test_images).to(device)
         x_0 = torch.randn(batch_size, *test_images.shape[1:], device=device)
-        x, nfe = _euler_conditional(model, x_0, con.float().contiguous(), steps)
+        if solver == "dopri5":
+            x, nfe = _dopri5_conditional(model, x_0, con, "con")
+        else:
+            x, nfe = _euler_conditional(model, x_0, con.float().contiguous(), steps)
         traj = default_ops.clip_(x.view([-1, *test_images.shape[1:]]).contiguous(), -1.0, 1.0)
     model.train()
     return traj, con, nfe
 
 
-def generate_samples_eval_superres(model, test_images, batch_size=8, step=0, net_="normal", low_res_size=(16, 16), solver="euler",
+def generate_samples_eval_superres(model, test_images, batch_size=8, step=0, net_="normal", low_res_size=(16, 16), solver="dopri5",
                                    steps=100):
     """Super-resolution evaluation sampler (utils_mnist_hy.py:76-98, utils_mnist_hy2.py:148-169): (traj, low_res, nfe)."""
     _check_solver(solver)
@@ -115,7 +133,10 @@ def generate_samples_eval_superres(model, test_images, batch_size=8, step=0, net
     with torch.no_grad():
         low_res = downsample_images(test_images, low_res_size).to(device)
         x_0 = torch.randn(batch_size, *test_images.shape[1:], device=device)
-        x, nfe = _euler_conditional(model, x_0, low_res.float().contiguous(), steps)
+        if solver == "dopri5":
+            x, nfe = _dopri5_conditional(model, x_0, low_res, "low_res")
+        else:
+            x, nfe = _euler_conditional(model, x_0, low_res.float().contiguous(), steps)
         traj = default_ops.clip_(x.view([-1, *test_images.shape[1:]]).contiguous(), -1.0, 1.0)
     model.train()
     return traj, low_res, nfe

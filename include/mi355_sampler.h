@@ -202,6 +202,18 @@ int mi355_to_unit_range(const float* x, float* out, int64_t n, void* stream);
 /* N(0,1) fill from the device Philox4x32-10 stream (seed, offset) */
 int mi355_randn(float* out, uint64_t seed, uint64_t offset, int64_t n, void* stream);
 
+/* Adaptive Dormand-Prince 5(4) building blocks (torchdiffeq.odeint(method="dopri5"): cifar10/compute_fid.py:80-85,
+ * mnist/utils_mnist.py:101-108; un-vendored, algorithm restated).  The step-size controller runs on the host.
+ *   rk_combine: out = y0 + sum_j coeff_host[j] * k_j   (coefficients already multiplied by dt; y0 may be NULL)
+ *   rk_sqnorm : *out += sum_i ((a_i - sub_i) / (atol + rtol * max(|b_i|, |b2_i|)))^2   (sub, b, b2 may be NULL; fp64)
+ *   rk_interp : torchdiffeq's quartic dense output at x = (t - t0) / dt                                   */
+int mi355_rk_combine(float* out, const float* y0, const float* k0, const float* k1, const float* k2, const float* k3, const float* k4,
+                     const float* k5, const float* k6, const float* coeff_host, int nk, int64_t n, void* stream);
+int mi355_rk_sqnorm(const float* a, const float* sub, const float* b, const float* b2, float atol, float rtol, int64_t n, double* out,
+                    void* stream);
+int mi355_rk_interp(float* out, const float* y0, const float* y1, const float* y_mid, const float* f0, const float* f1, float dt, float x,
+                    int64_t n, void* stream);
+
 /* Standalone conv / attention ops on NCHW fp32 tensors for parity tests of the HIP kernels
  * (pack -> implicit-GEMM MFMA kernel -> unpack; `workspace` from mi355_op_workspace_bytes). */
 int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw);

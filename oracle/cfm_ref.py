@@ -78,3 +78,75 @@ def painting_loss(x: torch.Tensor, condition: torch.Tensor, pad_value: float = -
     x = torch.where(condition == pad_value, 0.0, x)
     c = torch.where(condition == pad_value, 0.0, condition)
     return torch.sum((x - c) ** 2, dim=(1, 2, 3))
+
+
+# --- adaptive Dormand-Prince 5(4): torchdiffeq.odeint(method="dopri5") restated (un-vendored, version unpinned) ------------
+_DP_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+_DP_BETA = [[1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9], [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+            [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656], [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]]
+_DP_CERR = [35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720, -2187 / 6784 - -12231 / 42400,
+            11 / 84 - 649 / 6300, -1.0 / 60.0]
+_DP_CMID = [6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+            187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+
+
+@torch.no_grad()
+def dopri5(func, y0, t0: float, t_end: float, rtol: float, atol: float):
+    """odeint(func, y0, [t0, t_end], rtol, atol, method="dopri5")[-1] as called at cifar10/compute_fid.py:80-85 and
+    mnist/utils_mnist.py:101-108.  `y0` is a tensor or a tuple of tensors (tuple states use the max of the per-component
+    RMS norms).  Returns (y(t_end), nfe).  Published torchdiffeq 0.2.x algorithm; no reference test pins it."""
+    tup = isinstance(y0, (tuple, list))
+    ys = [v.float() for v in (y0 if tup else [y0])]
+    nfe = [0]
+
+    def f(t, y):
+        nfe[0] += 1
+        out = func(torch.tensor(t), tuple(y)) if tup else [func(torch.tensor(t), y[0])]
+        return [o.float() for o in out]
+
+    def norm(vs):
+        return max(float(v.double().pow(2).mean().sqrt()) for v in vs)
+
+    def comb(base, ks, cs):
+        out = []
+        for i in range(len(ys)):
+            acc = torch.zeros_like(ks[0][i])
+            for k, c in zip(ks, cs):
+                acc = acc + k[i] * c
+            out.append(acc if base is None else base[i] + acc)
+        return out
+
+    f0 = f(t0, ys)
+    scale = [atol + v.abs() * rtol for v in ys]
+    d0 = norm([v / s for v, s in zip(ys, scale)])
+    d1 = norm([v / s for v, s in zip(f0, scale)])
+    h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    f1 = f(t0 + h0, comb(ys, [f0], [h0]))
+    d2 = norm([(a - b) / s for a, b, s in zip(f1, f0, scale)]) / h0
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** 0.2
+    dt = min(100 * h0, h1)
+    t, interp = t0, None
+    while t_end > t:
+        t1 = t + dt
+        ks = [f0]
+        yi = None
+        for a, beta in zip(_DP_ALPHA, _DP_BETA):
+            yi = comb(ys, ks, [b * dt for b in beta])
+            ks.append(f(t1 if a == 1.0 else t + a * dt, yi))
+        y1, f1 = yi, ks[-1]
+        err = comb(None, ks, [c * dt for c in _DP_CERR])
+        ratio = norm([e / (atol + rtol * torch.max(a.abs(), b.abs())) for e, a, b in zip(err, ys, y1)])
+        if ratio <= 1.0:
+            interp = (ys, y1, comb(ys, ks, [c * dt for c in _DP_CMID]), f0, f1, t, dt)
+            t, ys, f0 = t1, y1, f1
+        factor = 10.0 if ratio == 0.0 else min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))
+        dt = dt * factor
+    ya, yb, ym, fa, fb, ta, dta = interp
+    x = (t_end - ta) / dta
+    out = []
+    for i in range(len(ya)):
+        a = 2 * dta * (fb[i] - fa[i]) - 8 * (yb[i] + ya[i]) + 16 * ym[i]
+        b = dta * (5 * fa[i] - 3 * fb[i]) + 18 * ya[i] + 14 * yb[i] - 32 * ym[i]
+        c = dta * (fb[i] - 4 * fa[i]) - 11 * ya[i] - 5 * yb[i] + 16 * ym[i]
+        out.append((((a * x + b) * x + c) * x + dta * fa[i]) * x + ya[i])
+    return (tuple(out) if tup else out[0]), nfe[0]

@@ -242,4 +242,4 @@ def test_mnist_patch_sampler():
         ys, xs = torch.where(c[k, 0] == -2)
         assert ys.min() >= 5 and xs.min() >= 5 and ys.max() - ys.min() == 13 and xs.max() - xs.min() == 13
     with pytest.raises(NotImplementedError):
-        utils_mnist.generate_samples(torch.nn.Identity(), False, "/tmp/", 0, solver="dopri5")
+        utils_mnist.generate_samples(torch.nn.Identity(), False, "/tmp/", 0, solver="rk4")
