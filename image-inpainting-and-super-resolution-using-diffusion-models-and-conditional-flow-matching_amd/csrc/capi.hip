@@ -312,13 +312,31 @@ int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, fl
   d.dbg = p;
 #endif
   if ((rc = conv_launch(d, s))) return rc;
+  if (const char* reps_s = getenv("MI355_CONV_TIME")) {   // diagnostic: average duration of the conv launch alone
+    const int reps = atoi(reps_s) > 0 ? atoi(reps_s) : 20;
+    hipEvent_t e0, e1;
+    MI355_CHECK_HIP(hipEventCreate(&e0)); MI355_CHECK_HIP(hipEventCreate(&e1));
+    MI355_CHECK_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) if ((rc = conv_launch(d, s))) return rc;
+    MI355_CHECK_HIP(hipEventRecord(e1, s));
+    MI355_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MI355_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / reps, fl = 2.0 * batch * g.Ho * g.Wo * (double)cout * cin * ksize * ksize;
+    fprintf(stderr, "[conv time] %d launches, %.1f us each, %.0f TFLOP/s\n", reps, us, fl / us * 1e-6);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
   if (nhwc && (rc = unpack_nchw_launch(dtype, yout, batch, g.Ho * g.Wo, cout, y, s))) return rc;
   MI355_CHECK_HIP(hipStreamSynchronize(s));  // `packed` is a temporary host buffer
 #ifdef CONV_STAMPS
   {
     std::vector<unsigned long long> hv(nwaves * 8);
     MI355_CHECK_HIP(hipMemcpy(hv.data(), p, nwaves * 64, hipMemcpyDeviceToHost));
-    static const char* names[8] = {"setup", "commit_patch", "barrier_A", "commit_w(+vmcnt)", "barrier_B", "prefetch_issue", "mma", "epilogue"};
+    static const char* names_plain[8] = {"setup", "commit_patch", "barrier_A", "commit_w(+vmcnt)", "barrier_B", "prefetch_issue", "mma", "epilogue"};
+    // warp-specialised kernel: slots 0-4 are written by loader waves only, 5-7 by consumer waves only (half the waves each)
+    static const char* names_ws[8] = {"L:fill", "L:commit_w", "L:commit_frag", "L:issue", "L:barrier", "C:barrier", "C:mma_row", "C:epilogue+setup"};
+    const bool ws_names = !getenv("MI355_CONV_WS") || atoi(getenv("MI355_CONV_WS")) != 0;
+    const char** names = ws_names ? names_ws : names_plain;
     double h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
     for (size_t w = 0; w < nwaves; ++w) for (int k = 0; k < 8; ++k) h[k] += (double)hv[w * 8 + k];
     for (int k = 0; k < 8; ++k) tot += h[k];

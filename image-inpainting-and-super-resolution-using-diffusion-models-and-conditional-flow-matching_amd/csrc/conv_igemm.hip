@@ -526,6 +526,8 @@ int launch_cfg(const ConvKArgs& a, int BM, int BN, int ks, int pit, dim3 grid, s
   return -4;
 }
 
+#include "conv_ws.inc.h"
+
 struct Geo {
   int Hc, Wc, Ho, Wo, BM, BN, bn_pack, lvw, lth, G, PW, PH, NP, tiles_x, tiles_y, groups, pad, stride, plane_bytes, pit, pit_t;
   size_t lds;
@@ -679,6 +681,10 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   a.lvw = g.lvw; a.lth = g.lth; a.G = g.G; a.PW = g.PW; a.PH = g.PH; a.NP = g.NP;
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
   dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
+  {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
+    const int r = d.dtype == 0 ? launch_ws<float>(a, g.BM, g.BN, d.ks, stream) : launch_ws<bf16>(a, g.BM, g.BN, d.ks, stream);
+    if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
+  }
   int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream)
                         : launch_cfg<bf16>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream);
   if (rc) return rc;

@@ -69,6 +69,49 @@ __global__ void __launch_bounds__(128) linear_kernel(const float* __restrict__ i
   }
 }
 
+// Small-batch form (the sampler loops share one step time, so B = 1): a GEMV is latency-bound, so the K range is split
+// over the 4 waves of a workgroup (lanes own 64 consecutive outputs, 8 independent loads in flight per lane) and the
+// partial sums meet in LDS.
+__global__ void __launch_bounds__(256) linear_small_kernel(const float* __restrict__ in, const float* __restrict__ Wt,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int B, int K, int J,
+                                                           int in_act, int out_act) {
+  __shared__ float part[4][LB][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int kq = K / 4, k0 = wave * kq;
+  float acc[LB];
+#pragma unroll
+  for (int r = 0; r < LB; ++r) acc[r] = 0.f;
+  if (j < J) {
+    for (int k = k0; k < k0 + kq; k += 8) {
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = Wt[(size_t)(k + u) * J + j];
+#pragma unroll
+      for (int r = 0; r < LB; ++r) {
+        if (r < B) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            float x = in[(size_t)r * K + k + u];
+            if (in_act) x = silu_f<false>(x);
+            acc[r] = fmaf(x, w[u], acc[r]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LB; ++r) part[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (wave == 0 && j < J) {
+    const float bj = bias ? bias[j] : 0.f;
+    for (int r = 0; r < B; ++r) {
+      const float v = part[0][r][lane] + part[1][r][lane] + part[2][r][lane] + part[3][r][lane] + bj;
+      out[(size_t)r * J + j] = out_act ? silu_f<false>(v) : v;
+    }
+  }
+}
+
 template <typename T>
 __global__ void pack_nhwc_kernel(const float* x, int Cx, const float* cond, int Cc, int N, int HW, int Cpad, T* out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,6 +172,11 @@ int timestep_embedding_launch(const float* t, int B, int dim, float max_period, 
 
 int linear_launch(const float* in, const float* Wt, const float* bias, float* out, int B, int K, int J, int in_act, int out_act,
                   hipStream_t s) {
+  if (B <= LB && K % 32 == 0) {
+    hipLaunchKernelGGL(linear_small_kernel, dim3((J + 63) / 64), dim3(256), 0, s, in, Wt, bias, out, B, K, J, in_act, out_act);
+    MI355_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 grid((J + 127) / 128, (B + LB - 1) / LB);
   MI355_REQUIRE(K % 4 == 0 && (size_t)LB * K * 4 <= 64 * 1024, -4, "linear: K must be a multiple of 4 and <= 2048");
   hipLaunchKernelGGL(linear_kernel, grid, dim3(128), (size_t)LB * K * 4, s, in, Wt, bias, out, B, K, J, in_act, out_act);

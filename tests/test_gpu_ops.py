@@ -59,6 +59,11 @@ CONV_CASES = [
     (2, 256, 8, 8, 128, 1, 1, 0),     # skip 1x1
     (1, 32, 64, 64, 64, 3, 1, 0),
     (1, 32, 128, 128, 32, 3, 1, 0),   # one tile row per workgroup
+    # bench-sized launches (>= 512 workgroups of 128 pixels x 128 channels): the warp-specialised persistent kernel
+    (64, 128, 32, 32, 128, 3, 1, 0),
+    (64, 64, 32, 32, 256, 3, 1, 0),   # two channel tiles per pixel tile
+    (64, 128, 16, 16, 128, 3, 1, 2),  # nearest x2 gather
+    (80, 64, 28, 28, 128, 3, 1, 0),   # ragged tiles, tile count not a multiple of the persistent grid
 ]
 
 
@@ -87,7 +92,7 @@ def test_conv2d(ops, case, dtype, rtol, atol):
 @pytest.mark.parametrize("dtype,rtol,atol", [(_lib.MI355_F32, 5e-5, 5e-5), (_lib.MI355_BF16, 3e-2, 3e-2)])
 def test_gn_silu_conv_fused(ops, silu, dtype, rtol, atol):
     """GroupNorm32 (+SiLU) folded into the conv's staging prologue == ResBlock in_layers (unet.py:283-286)."""
-    for (B, C, H, Co) in [(2, 64, 16, 128), (3, 96, 8, 64), (9, 32, 4, 32)]:
+    for (B, C, H, Co) in [(2, 64, 16, 128), (3, 96, 8, 64), (9, 32, 4, 32), (70, 128, 32, 128)]:
         x = randn(C + H, B, C, H, H) * 1.5 + 0.2
         sd = synth_state_dict({"in_layers.0.weight": (C,), "in_layers.0.bias": (C,), "weight": (Co, C, 3, 3), "bias": (Co,)}, C)
         h = unet_ref.group_norm32(x, sd["in_layers.0.weight"], sd["in_layers.0.bias"])

@@ -82,6 +82,22 @@ def test_batch_independence_and_large_batch():
         torch.testing.assert_close(y[k:k + 1], yk, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+def test_headline_unet_bench_batch_matches_single_images(precision, tol):
+    """BASELINE configs[1] network at a bench-sized batch (the large-tile / persistent kernels are only chosen when a launch
+    has >= 512 workgroups) against the same images run alone (small-tile kernels, pinned to the oracle by the tests above)."""
+    cfg = unet_ref.UNetConfig(32, 3, 128, 3, 2, (2,), channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
+    net, _ = build(cfg, 77, precision)
+    B = 96
+    x = randn(5, B, 3, 32, 32).to(DEV)
+    t = torch.linspace(0, 1, B).to(DEV)
+    y = net(x, t)
+    assert torch.isfinite(y).all()
+    for k in (0, 41, 95):
+        yk = net(x[k:k + 1].contiguous(), t[k:k + 1].contiguous())
+        torch.testing.assert_close(y[k:k + 1], yk, rtol=tol, atol=tol)
+
+
 def _tiny(in_ch, out_ch, seed, precision):
     cfg = unet_ref.UNetConfig(16, in_ch, 32, out_ch, 1, (2,), channel_mult=(1, 2), num_heads=2)
     net, sd = build(cfg, seed, precision)
