@@ -2,29 +2,39 @@
 //
 // Measured on the plain kernel (in-kernel stamps + ablations): its phases (patch staging + GN/SiLU
 // prologue, weight staging, MFMA rows, epilogue stores) simply ADD UP - two co-resident workgroups run them in lockstep
-// and a wave is in-order, so the MFMA pipe idles ~70 % of the time.  Here the overlap is built in:
+// and a wave is in-order, so the MFMA pipe idles ~70 % of the time.  Ablations of the first warp-specialised version
+// (tools/ws_ablate.sh) then showed what a 128-pixel tile cannot hide: 24 KB of weights per kernel row per workgroup
+// through `ds_write_b128` (13 cycles per wave-instruction) and through the CU's 64 B/clk L1 path.  Hence:
+//   * tile = 256 pixels (16 x 16) x 128 output channels: weight bytes per MFMA halve; halo 324 / 256 = 1.27x;
 //   * one 8-wave workgroup per CU; waves 0-3 are LOADERS (global -> registers -> prologue -> LDS), waves 4-7 are
-//     CONSUMERS (LDS -> MFMA -> epilogue).  Each SIMD hosts one of each: VALU / VMEM / LDS-write work next to MFMA work;
+//     CONSUMERS (LDS -> MFMA -> epilogue), 128 pixels x 64 channels each.  Every SIMD hosts one of each;
 //   * persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ...; the loaders treat the whole walk as ONE stream of
 //     (tile, chunk, kernel row) items and run ahead of the consumers across tile boundaries:
-//        global loads  : 2 chunks (6 kernel rows) ahead, in register rings (patch fragments, weight rows, GN (a, b))
-//        LDS commits   : patch chunk q+1 is transformed and written (one fragment per kernel row) while the consumers
+//        global loads  : patch fragments and GN (a, b) 1 chunk (3 rows) ahead, weight rows 2 rows ahead (register rings)
+//        LDS commits   : patch chunk q+1 is transformed and written (two fragments per kernel row) while the consumers
 //                        multiply chunk q (3 patch planes); weight row g+1 while they multiply row g (2 buffers)
-//     so HBM/L2 latency, the prologue VALU work and the LDS writes all sit beside the MFMA rows, ONE barrier per row;
-//   * the tile is 8 x 16 pixels (10 x 18 = 180 patch pixels = exactly 3 fragments per loader thread, 1.4x halo)
-//     instead of the plain kernel's 4 x 32 (204 pixels -> 4 fragments, 1.6x halo): 25 % less prologue work.
+//     ONE workgroup barrier per kernel row;
+//   * the consumers run a register-double-buffered pipeline of half-taps (16 MFMAs each): the LDS reads of step s+1 are
+//     issued before the MFMAs of step s, and the barrier of the next row sits between the last reads and the last
+//     MFMAs of the current row, so neither LDS latency nor the barrier stalls the matrix pipe.
 // Every wave reaches every barrier of the schedule (both roles execute exactly one barrier per kernel row of every tile).
 #ifndef WS_ABLATE
 #define WS_ABLATE 0   // diagnostic builds only: 4 = consumers skip LDS reads + MFMA, 8 = no weight loads, 16 = no patch loads, 64 = no weight LDS writes
 #endif
-template <typename T, int PIT, bool PRO>
+namespace ws {
+constexpr int VW = 16, TH = 16, PW = VW + 2, PH = TH + 2, NPX = PW * PH;   // 18 x 18 = 324 patch pixels
+constexpr int PIT = 6, FR = 64, PLANE = PIT * FR * PROW;                    // 36,864 B per patch plane
+constexpr int AROWB = PW * PROW;                                            // bytes between patch rows
+constexpr int BN = 128, WTILE = BN * 64, WIT = 3 * WTILE / (256 * 16);      // 6 x 16 B per loader thread per kernel row
+constexpr size_t LDS_BYTES = 3 * (size_t)PLANE + 2 * 3 * (size_t)WTILE;     // 159,744 B
+}  // namespace ws
+
+template <typename T, bool PRO>
 __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_mt, int n_nt) {
+  using namespace ws;
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK, ESZ = sizeof(T);
   constexpr bool FAST = (E::DTYPE == 1);
-  constexpr int BN = 128, WN = 2, WTM = 64, WTN = 64, MI = 4, NI = 4;
-  constexpr int WTILE = BN * 64, WIT = 3 * WTILE / (256 * 16), FR = 64, PLANE = PIT * FR * PROW;
-  static_assert(PIT == 3, "one patch fragment per kernel row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* pbuf = smem;                 // 3 patch planes
   char* wbuf = smem + 3 * PLANE;     // 2 x (3 weight tiles)
@@ -48,7 +58,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   auto origin = [&](int mt, int& n0, int& y0, int& x0) {
     const int ng = mt / tpi, rem = mt - ng * tpi;
     const int tyi = rem / p.tiles_x, txi = rem - tyi * p.tiles_x;
-    n0 = ng; y0 = tyi << p.lth; x0 = txi << p.lvw;
+    n0 = ng; y0 = tyi * TH; x0 = txi * VW;
   };
   int t_first = (int)blockIdx.x - (int)gridDim.x;
   t_first = next_valid(t_first);
@@ -61,8 +71,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wbytes, 0x00020000);
     const int fq = tid & 3, frow = tid >> 2;
     const int pro = (!PRO || (p.ablate & 2)) ? 0 : (p.pro_silu ? 2 : 1);
-    const int pimg = p.PH * p.PW;
-    const float inv_pw = 1.0f / (float)p.PW;
     uint32_t woff[WIT];
 #pragma unroll
     for (int i = 0; i < WIT; ++i) woff[i] = (i * 256 + tid) * 16;
@@ -78,8 +86,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       for (int u = 0; u < PIT; ++u) {
         const int i = frow + u * FR;
         int s = -1;
-        if (i < pimg) {
-          const int py = (int)(((float)i + 0.5f) * inv_pw), px = i - py * p.PW;   // exact: i < 256, PW <= 18
+        if (i < NPX) {
+          const int py = (int)(((float)i + 0.5f) * (1.0f / (float)PW)), px = i - py * PW;   // exact: i < 384
           const int cy = cy0 + py, cx = cx0 + px;
           if (cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
             if (p.mode == CONV_UP2) s = (n0 * p.Hs + (cy >> 1)) * p.Ws + (cx >> 1);
@@ -100,37 +108,41 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         if (ld_t < ntp) { int mt, nt; decode(ld_t, mt, nt); setup(mt); }
       }
     };
-    u32x4 raw[2][PIT] = {}; float pa[2][V] = {}, pb[2][V] = {};
+    u32x4 raw[PIT] = {};                                  // fragment u of the chunk that is committed next
+    float pa[V] = {}, pb[V] = {}, pan[V] = {}, pbn[V] = {};   // GN (a, b) of that chunk / of the one after it
     // Every load below is issued unconditionally (a finished stream keeps re-reading its last valid addresses and the data
     // is never committed): a load under a branch makes the compiler's s_waitcnt bookkeeping assume the shortest queue,
     // i.e. vmcnt(0) at every use, which would drain the whole run-ahead.
-    auto issue_frag = [&](auto slotc, auto uc) {
-      constexpr int slot = decltype(slotc)::value, u = decltype(uc)::value;
+    auto issue_frag = [&](auto uc) {
+      constexpr int u = decltype(uc)::value;
       const int cb = ld_c * CHUNK;
       const bool first = cb < p.C0;
-      if constexpr (!(WS_ABLATE & 16)) raw[slot][u] = buf_load16(first ? rs0 : rs1, first ? voff0[u] : voff1[u], (first ? cb : cb - p.C0) * ESZ);
+      if constexpr (!(WS_ABLATE & 16)) raw[u] = buf_load16(first ? rs0 : rs1, first ? voff0[u] : voff1[u], (first ? cb : cb - p.C0) * ESZ);
     };
-    auto issue_ab = [&](auto slotc) {
-      constexpr int slot = decltype(slotc)::value;
+    auto issue_ab = [&]() {
       if constexpr (PRO) {
         const float* ap = p.pro_a + (size_t)n0_ld * p.Cin + ld_c * CHUNK + fq * V;
         const float* bp = p.pro_b + (size_t)n0_ld * p.Cin + ld_c * CHUNK + fq * V;
 #pragma unroll
-        for (int j = 0; j < V; ++j) { pa[slot][j] = ap[j]; pb[slot][j] = bp[j]; }
+        for (int j = 0; j < V; ++j) { pan[j] = ap[j]; pbn[j] = bp[j]; }
       }
     };
-    auto commit_frag = [&](auto slotc, auto uc, int plane, uint32_t mask) {
-      constexpr int slot = decltype(slotc)::value, u = decltype(uc)::value;
-      u32x4 outv = raw[slot][u];
+    auto take_ab = [&]() {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { pa[j] = pan[j]; pb[j] = pbn[j]; }
+    };
+    auto commit_frag = [&](auto uc, int plane, uint32_t mask) {
+      constexpr int u = decltype(uc)::value;
+      u32x4 outv = raw[u];
       if (pro) {
         float f[V];
-        frag_to_float(raw[slot][u], f, T());
+        frag_to_float(raw[u], f, T());
         if (pro == 2) {
 #pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = silu_fast<FAST>(pa[slot][j] * f[j] + pb[slot][j]);
+          for (int j = 0; j < V; ++j) f[j] = silu_fast<FAST>(pa[j] * f[j] + pb[j]);
         } else {
 #pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = pa[slot][j] * f[j] + pb[slot][j];
+          for (int j = 0; j < V; ++j) f[j] = pa[j] * f[j] + pb[j];
         }
         outv = float_to_frag(f, T());
         if (!((mask >> u) & 1u)) outv = u32x4{0u, 0u, 0u, 0u};   // zero padding applies AFTER the prologue
@@ -138,10 +150,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       *reinterpret_cast<u32x4*>(pbuf + plane * PLANE + (frow + u * FR) * PROW + fq * 16) = outv;
     };
 
-    // ---- weight stream: 6 kernel rows ahead of the row being committed ----
+    // ---- weight stream: 2 kernel rows ahead of the row being committed ----
     int wl_t = t_first, wl_row = 0, wl_nt;
     { int mt; decode(wl_t, mt, wl_nt); }
-    u32x4 wreg[6][WIT] = {};
+    u32x4 wreg[2][WIT] = {};
     auto prefetch_w = [&](auto slotc) {
       constexpr int slot = decltype(slotc)::value;
       const uint32_t so = ((uint32_t)wl_nt * p.nchunks * 9 + (uint32_t)wl_row * 3) * WTILE;
@@ -165,49 +177,55 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     };
 
     STAMP_DECL
-    // ---- fill the pipeline: chunks 0, 1 and rows 0..5 in flight, chunk 0 committed ----
-    issue_frag(IC<0>(), IC<0>()); issue_frag(IC<0>(), IC<1>()); issue_frag(IC<0>(), IC<2>()); issue_ab(IC<0>());
-    ld_advance();
-    issue_frag(IC<1>(), IC<0>()); issue_frag(IC<1>(), IC<1>()); issue_frag(IC<1>(), IC<2>()); issue_ab(IC<1>());
+    // ---- fill the pipeline: chunk 0 committed, chunk 1 and rows 0, 1 in flight ----
+    issue_frag(IC<0>()); issue_frag(IC<1>()); issue_frag(IC<2>()); issue_frag(IC<3>()); issue_frag(IC<4>()); issue_frag(IC<5>());
+    issue_ab();
+    prefetch_w(IC<0>()); prefetch_w(IC<1>());
     uint32_t vmask_cm = vmask_ld;      // chunks 0 and 1 belong to the first tile (nchunks >= 2)
-    prefetch_w(IC<0>()); prefetch_w(IC<1>()); prefetch_w(IC<2>()); prefetch_w(IC<3>()); prefetch_w(IC<4>()); prefetch_w(IC<5>());
+    take_ab();
     ld_advance();
-    commit_frag(IC<0>(), IC<0>(), 0, vmask_cm); issue_frag(IC<0>(), IC<0>());
-    commit_frag(IC<0>(), IC<1>(), 0, vmask_cm); issue_frag(IC<0>(), IC<1>());
-    commit_frag(IC<0>(), IC<2>(), 0, vmask_cm); issue_frag(IC<0>(), IC<2>());
-    issue_ab(IC<0>());
+    commit_frag(IC<0>(), 0, vmask_cm); issue_frag(IC<0>());
+    commit_frag(IC<1>(), 0, vmask_cm); issue_frag(IC<1>());
+    commit_frag(IC<2>(), 0, vmask_cm); issue_frag(IC<2>());
+    commit_frag(IC<3>(), 0, vmask_cm); issue_frag(IC<3>());
+    commit_frag(IC<4>(), 0, vmask_cm); issue_frag(IC<4>());
+    commit_frag(IC<5>(), 0, vmask_cm); issue_frag(IC<5>());
+    issue_ab();
 
     STAMP(0)
     int gcnt = 0, plane = 1;           // next weight buffer parity; plane the NEXT chunk is committed into
     for (int t = t_first; t < ntp;) {
       const int t_next = next_valid(t);
-      // one chunk of the consumer stream: its three weight rows + the commit of the chunk AFTER it
-      auto body = [&](int c, auto ws0c, auto psc) {
-        constexpr int WS0 = decltype(ws0c)::value, PS = decltype(psc)::value;
+      // one chunk of the consumer stream: its three weight rows + the commit of the chunk AFTER it (whose fragments were
+      // loaded one chunk ago; each is replaced by the same fragment of the chunk after that as soon as it is committed)
+      auto body = [&](int c, auto cpc) {
+        constexpr int CP = decltype(cpc)::value;   // chunk parity: weight register slot of row (c, ky) = (3 * CP + ky) & 1
         bool nx_ok = true;
-        if (c + 1 == p.nchunks) {      // the next chunk opens the next tile; the load stream is at its chunk 1
+        if (c + 1 == p.nchunks) {      // the next chunk opens the next tile; the load stream is at that chunk
           nx_ok = t_next < ntp;
           vmask_cm = vmask_ld;
         }
-        ld_advance();                  // -> two chunks after the chunk committed below
+        take_ab();
+        ld_advance();                  // -> the chunk after the one committed below
         auto interval = [&](auto kyc) {
-          constexpr int ky = decltype(kyc)::value;
-          commit_w(IC<WS0 + ky>(), gcnt & 1); ++gcnt;
+          constexpr int ky = decltype(kyc)::value, slot = (3 * CP + ky) & 1;
+          commit_w(IC<slot>(), gcnt & 1); ++gcnt;
           STAMP(1)
-          prefetch_w(IC<WS0 + ky>());
+          prefetch_w(IC<slot>());
           STAMP(3)
-          if (nx_ok) commit_frag(IC<PS>(), IC<ky>(), plane, vmask_cm);
+          if (nx_ok) commit_frag(IC<2 * ky>(), plane, vmask_cm);
+          issue_frag(IC<2 * ky>());
+          if (nx_ok) commit_frag(IC<2 * ky + 1>(), plane, vmask_cm);
+          issue_frag(IC<2 * ky + 1>());
+          if (ky == 2) issue_ab();
           STAMP(2)
-          issue_frag(IC<PS>(), IC<ky>());
-          if (ky == 2) issue_ab(IC<PS>());
-          STAMP(3)
           __syncthreads();             // kernel row (t, c, ky) is in LDS; after ky == 2 so is the next chunk's patch
           STAMP(4)
         };
         interval(IC<0>()); interval(IC<1>()); interval(IC<2>());
         plane = plane == 2 ? 0 : plane + 1;
       };
-      for (int c = 0; c < p.nchunks; c += 2) { body(c, IC<0>(), IC<1>()); body(c + 1, IC<3>(), IC<0>()); }
+      for (int c = 0; c < p.nchunks; c += 2) { body(c, IC<0>()); body(c + 1, IC<1>()); }
       t = t_next;
     }
     STAMP_FLUSH
@@ -215,87 +233,87 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     // ================================= CONSUMER waves =================================
     __builtin_amdgcn_s_setprio(2);     // the MFMA stream goes first when both waves of a SIMD are ready
     const int wave = wave8 - 4;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave >> 1, wn = wave & 1;   // pixel rows 8*wm .. 8*wm+7 of the tile, channels 64*wn .. 64*wn+63
     const int lr = lane & 15, lq = lane >> 4;
-    const int VWm = (1 << p.lvw) - 1, THm = (1 << p.lth) - 1;
-    int arow[MI], a1[MI], a2[MI], brow[NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = wm * WTM + mi * 16 + lr;
-      const int tx = m & VWm, ty = (m >> p.lvw) & THm;
-      arow[mi] = (ty * p.PW + tx) * PROW + lq * 16;
-      a1[mi] = arow[mi] + p.PW * PROW; a2[mi] = arow[mi] + 2 * p.PW * PROW;
-    }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int row = wn * WTN + ni * 16 + lr;
-      brow[ni] = row * 64 + 16 * (lq ^ ((row >> 1) & 3));
-    }
+    const int a_base = (wm * 8 * PW + lr) * PROW + lq * 16;                 // + mi * AROWB (+ ky * AROWB + kx * PROW)
+    const int b_base = (wn * 64 + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));   // + ni * 1024 (+ kx * WTILE)
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (p.ablate & 1) ? 0u : p.obytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.out), 0, p.rbytes, 0x00020000);
     constexpr bool PAIR = E::DTYPE == 1;
-    constexpr int NP2 = PAIR ? NI / 2 : NI, PSTEP = PAIR ? 32 : 16;
+    constexpr int NI = 4, NP2 = PAIR ? NI / 2 : NI, PSTEP = PAIR ? 32 : 16;
 
-    int gcnt = 0, plane = 0;
+    f32x4 acc[8][NI];
+    u32x4 af[2][4], bf[2][4];
     STAMP_DECL
-    for (int t = t_first; t < ntp; t = next_valid(t)) {
+    // row state of the stream of kernel rows (continuous across chunks and tiles)
+    int ky = 0, plane = 0, sel = 0, a_cur = a_base, b_cur = b_base;
+    auto advance_row = [&]() {
+      sel ^= 1;
+      if (++ky == 3) { ky = 0; plane = plane == 2 ? 0 : plane + 1; }
+      a_cur = a_base + plane * PLANE + ky * AROWB;
+      b_cur = b_base + sel * (3 * WTILE);
+    };
+    auto read_a = [&](auto bufc, auto halfc, auto kxc) {
+      constexpr int buf = decltype(bufc)::value, half = decltype(halfc)::value, kx = decltype(kxc)::value;
+      if constexpr (WS_ABLATE & 4) return;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[buf][j] = *reinterpret_cast<const u32x4*>(pbuf + a_cur + (half * 4 + j) * AROWB + kx * PROW);
+    };
+    auto read_b = [&](auto bufc, auto kxc) {
+      constexpr int buf = decltype(bufc)::value, kx = decltype(kxc)::value;
+      if constexpr (WS_ABLATE & 4) return;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[buf][ni] = *reinterpret_cast<const u32x4*>(wbuf + b_cur + kx * WTILE + ni * 1024);
+    };
+    // One half-tap: issue the LDS reads of the NEXT step, then the 16 MFMAs of this one.
+    //   R: row parity inside the unrolled row pair, s = 2 * kx + half, ZERO: first tap of a tile (accumulators start at 0)
+    auto step = [&](auto Rc, auto sc, auto zeroc, bool more_rows) {
+      constexpr int R = decltype(Rc)::value, s = decltype(sc)::value;
+      constexpr bool ZERO = decltype(zeroc)::value != 0;
+      constexpr int half = s & 1, kx = s >> 1, bpar = (R + kx) & 1;
+      if constexpr (s < 5) {
+        constexpr int s1 = s + 1, half1 = s1 & 1, kx1 = s1 >> 1;
+        read_a(IC<half1>(), IC<half1>(), IC<kx1>());
+        if constexpr (half1 == 0) read_b(IC<(R + kx1) & 1>(), IC<kx1>());
+      } else {
+        if (more_rows) {
+          STAMP(6)
+          __syncthreads();             // the next kernel row is staged; every read of this row has been issued and has landed
+          STAMP(5)
+          advance_row();
+          read_a(IC<0>(), IC<0>(), IC<0>());
+          read_b(IC<(R + 1) & 1>(), IC<0>());
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(WS_ABLATE & 4)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (ZERO) acc[half * 4 + j][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16(acc[half * 4 + j][ni], bf[bpar][ni], af[half][j], T());   // D rows = channels, cols = pixels
+          }
+      } else if constexpr (ZERO) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[half * 4 + j][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    __syncthreads();                   // kernel row 0 of the first tile is staged
+    STAMP(5)
+    read_a(IC<0>(), IC<0>(), IC<0>());
+    read_b(IC<0>(), IC<0>());
+    for (int t = t_first; t < ntp;) {
+      const int t_next = next_valid(t);
       int mt, nt, n0, y0, x0;
       decode(t, mt, nt);
       origin(mt, n0, y0, x0);
-      f32x4 acc[MI][NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < p.nchunks; ++c) {
-        const char* patch = pbuf + plane * PLANE;
-        auto row = [&](const int (&ao)[MI]) {
-          STAMP(7)
-          __syncthreads();                   // the loaders have finished staging this kernel row
-          STAMP(5)
-          const char* wt = wbuf + (gcnt & 1) * (3 * WTILE);
-          ++gcnt;
-          if constexpr (WS_ABLATE & 4) return;
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            u32x4 a[MI], b[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(patch + ao[mi] + kx * PROW);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(wt + kx * WTILE + brow[ni]);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], b[ni], a[mi], T());
-          }
-        };
-        row(arow); STAMP(6) row(a1); STAMP(6) row(a2); STAMP(6)
-        plane = plane == 2 ? 0 : plane + 1;
-      }
-      // ---- epilogue (same as the plain kernel): all loads first, 16-byte stores ----
-      const int co_w = nt * BN + wn * WTN + 4 * lq;
-      const int co_s = PAIR ? nt * BN + wn * WTN + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;
-      uint32_t ovo[MI], rvo[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int m = wm * WTM + mi * 16 + lr;
-        const int tx = m & VWm, ty = (m >> p.lvw) & THm;
-        const int y = y0 + ty, x = x0 + tx;
-        const bool ok = y < p.Ho && x < p.Wo && co_s < p.Cout;
-        const uint32_t opix = (uint32_t)((n0 * p.Ho + y) * p.Wo + x);
-        ovo[mi] = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.obytes;
-        uint32_t rpix = opix;
-        if (p.res_mode == RES_UP2) rpix = (uint32_t)((n0 * p.Hr + (y >> 1)) * p.Wr + (x >> 1));
-        rvo[mi] = (ok && p.res_mode != RES_NONE) ? (rpix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.rbytes;
-      }
-      u32x4 rr[MI][NP2];
-      if (p.res_mode != RES_NONE) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int k = 0; k < NP2; ++k)
-            rr[mi][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, rvo[mi] + k * PSTEP * ESZ, 0, 0));
-      }
+      // epilogue operands that do not depend on the pixel: fetched now, used after the last row
+      const int co_w = nt * BN + wn * 64 + 4 * lq;
       f32x4 add4[NI];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -310,47 +328,87 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         }
         add4[ni] = v;
       }
+      for (int r = 0; r < ngr; r += 2) {
+        const bool last_pair = r + 2 >= ngr;
+        if (r == 0) { step(IC<0>(), IC<0>(), IC<1>(), true); step(IC<0>(), IC<1>(), IC<1>(), true); }
+        else { step(IC<0>(), IC<0>(), IC<0>(), true); step(IC<0>(), IC<1>(), IC<0>(), true); }
+        step(IC<0>(), IC<2>(), IC<0>(), true); step(IC<0>(), IC<3>(), IC<0>(), true);
+        step(IC<0>(), IC<4>(), IC<0>(), true); step(IC<0>(), IC<5>(), IC<0>(), true);
+        step(IC<1>(), IC<0>(), IC<0>(), true); step(IC<1>(), IC<1>(), IC<0>(), true);
+        step(IC<1>(), IC<2>(), IC<0>(), true); step(IC<1>(), IC<3>(), IC<0>(), true);
+        step(IC<1>(), IC<4>(), IC<0>(), true); step(IC<1>(), IC<5>(), IC<0>(), !last_pair || t_next < ntp);
+      }
+      STAMP(6)
+      // ---- epilogue: MFMA rows are channels and columns are pixels, so lane (lr, lq) holds 4 consecutive channels of
+      // pixel lr per 16x16 tile; bf16 pairs of channel tiles are merged into 16-byte stores by two v_permlane16_swap ----
+      const int co_s = PAIR ? nt * BN + wn * 64 + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;
+      auto epi_half = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        uint32_t ovo[4], rvo[4];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if constexpr (!PAIR) {
+        for (int j = 0; j < 4; ++j) {
+          const int y = y0 + wm * 8 + h * 4 + j, x = x0 + lr;
+          const bool ok = y < p.Ho && x < p.Wo && co_s < p.Cout;
+          const uint32_t opix = (uint32_t)((n0 * p.Ho + y) * p.Wo + x);
+          ovo[j] = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.obytes;
+          uint32_t rpix = opix;
+          if (p.res_mode == RES_UP2) rpix = (uint32_t)((n0 * p.Hr + (y >> 1)) * p.Wr + (x >> 1));
+          rvo[j] = (ok && p.res_mode != RES_NONE) ? (rpix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.rbytes;
+        }
+        u32x4 rr[4][NP2];
+        if (p.res_mode != RES_NONE) {
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            f32x4 o = f32x4{acc[mi][ni][0] + add4[ni][0], acc[mi][ni][1] + add4[ni][1], acc[mi][ni][2] + add4[ni][2], acc[mi][ni][3] + add4[ni][3]};
-            if (p.res_mode != RES_NONE) {
-              const f32x4 tt = __builtin_bit_cast(f32x4, rr[mi][ni]);
-              o = f32x4{o[0] + tt[0], o[1] + tt[1], o[2] + tt[2], o[3] + tt[3]};
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo[mi] + ni * 16 * ESZ, 0, 0);
-          }
-        } else {
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int k = 0; k < NP2; ++k) {
-            float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.res_mode != RES_NONE) {   // un-swap the 8-channel residual piece back to the accumulator layout
-              const auto s0 = __builtin_amdgcn_permlane16_swap(rr[mi][k][0], rr[mi][k][2], false, false);
-              const auto s1 = __builtin_amdgcn_permlane16_swap(rr[mi][k][1], rr[mi][k][3], false, false);
-              const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
+            for (int k = 0; k < NP2; ++k)
+              rr[j][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, rvo[j] + k * PSTEP * ESZ, 0, 0));
+        }
 #pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                ra[2 * j] = __builtin_bit_cast(float, xa[j] << 16); ra[2 * j + 1] = __builtin_bit_cast(float, xa[j] & 0xffff0000u);
-                rb[2 * j] = __builtin_bit_cast(float, xb[j] << 16); rb[2 * j + 1] = __builtin_bit_cast(float, xb[j] & 0xffff0000u);
+        for (int j = 0; j < 4; ++j) {
+          const int mi = h * 4 + j;
+          if constexpr (!PAIR) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              f32x4 o = f32x4{acc[mi][ni][0] + add4[ni][0], acc[mi][ni][1] + add4[ni][1], acc[mi][ni][2] + add4[ni][2], acc[mi][ni][3] + add4[ni][3]};
+              if (p.res_mode != RES_NONE) {
+                const f32x4 tt = __builtin_bit_cast(f32x4, rr[j][ni]);
+                o = f32x4{o[0] + tt[0], o[1] + tt[1], o[2] + tt[2], o[3] + tt[3]};
               }
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo[j] + ni * 16 * ESZ, 0, 0);
             }
-            bf16x4 ta, tb;
+          } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              ta[j] = (bf16)(acc[mi][2 * k][j] + add4[2 * k][j] + ra[j]);
-              tb[j] = (bf16)(acc[mi][2 * k + 1][j] + add4[2 * k + 1][j] + rb[j]);
+            for (int k = 0; k < NP2; ++k) {
+              float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+              if (p.res_mode != RES_NONE) {   // un-swap the 8-channel residual piece back to the accumulator layout
+                const auto s0 = __builtin_amdgcn_permlane16_swap(rr[j][k][0], rr[j][k][2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(rr[j][k][1], rr[j][k][3], false, false);
+                const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                  ra[2 * q] = __builtin_bit_cast(float, xa[q] << 16); ra[2 * q + 1] = __builtin_bit_cast(float, xa[q] & 0xffff0000u);
+                  rb[2 * q] = __builtin_bit_cast(float, xb[q] << 16); rb[2 * q + 1] = __builtin_bit_cast(float, xb[q] & 0xffff0000u);
+                }
+              }
+              bf16x4 ta, tb;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                ta[q] = (bf16)(acc[mi][2 * k][q] + add4[2 * k][q] + ra[q]);
+                tb[q] = (bf16)(acc[mi][2 * k + 1][q] + add4[2 * k + 1][q] + rb[q]);
+              }
+              const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+              const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
+              const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
+              __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo[j] + k * PSTEP * ESZ, 0, 0);
             }
-            const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
-            const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
-            const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo[mi] + k * PSTEP * ESZ, 0, 0);
           }
         }
-      }
+      };
+      epi_half(IC<0>());
+      epi_half(IC<1>());
+      STAMP(7)
+      t = t_next;
     }
-    STAMP(7)
     STAMP_FLUSH
   }
 }
@@ -360,31 +418,24 @@ template <typename T>
 int launch_ws(ConvKArgs a, int BM, int BN, int ks, hipStream_t s) {
   static const int enabled = getenv("MI355_CONV_WS") ? atoi(getenv("MI355_CONV_WS")) : 1;
   if (!enabled || ks != 3 || BM != 128 || BN != 128 || a.G != 1 || a.bn_pack != 128 || a.out_mode != OUT_NHWC) return 1;
-  if (a.stride != 1 || a.nchunks < 2 || (a.nchunks & 1)) return 1;   // the register rings are unrolled over chunk pairs
-  // 8 x 16 (or 16 x 8) pixel tiles: 180 patch pixels
-  const int lw = ilog2_ceil(a.Wo), lh = ilog2_ceil(a.Ho);
-  a.lvw = lw < 4 ? lw : 4;
-  a.lth = 7 - a.lvw;
-  if (a.lth > lh || a.lth > 4) return 1;
-  const int VW = 1 << a.lvw, TH = 1 << a.lth;
-  a.PW = VW + 2; a.PH = TH + 2; a.NP = a.PW * a.PH;
-  if (a.NP > 3 * 64) return 1;
-  a.tiles_x = (a.Wo + VW - 1) / VW; a.tiles_y = (a.Ho + TH - 1) / TH;
+  if (a.stride != 1 || a.nchunks < 2 || (a.nchunks & 1)) return 1;   // row pairs (consumers) and chunk pairs (loaders) are unrolled
+  if (a.Wo < ws::VW || a.Ho < ws::TH) return 1;                       // 16 x 16 pixel tiles
+  a.lvw = 4; a.lth = 4; a.PW = ws::PW; a.PH = ws::PH; a.NP = ws::NPX;
+  a.tiles_x = (a.Wo + ws::VW - 1) / ws::VW; a.tiles_y = (a.Ho + ws::TH - 1) / ws::TH;
   const int n_mt = a.N * a.tiles_x * a.tiles_y, n_nt = (a.Cout + 127) / 128;
-  constexpr int PIT = 3;
-  auto kern = a.pro_a ? conv3x3_ws_kernel<T, PIT, true> : conv3x3_ws_kernel<T, PIT, false>;
+  static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; } return n; }();
+  if (n_mt * n_nt < ncu) return 1;                                    // fewer tiles than CUs: the plain kernel's smaller tiles fill the chip better
+  auto kern = a.pro_a ? conv3x3_ws_kernel<T, true> : conv3x3_ws_kernel<T, false>;
   static bool attr_done = false;
   if (!attr_done) {
-    for (auto k : {conv3x3_ws_kernel<T, PIT, true>, conv3x3_ws_kernel<T, PIT, false>}) {
+    for (auto k : {conv3x3_ws_kernel<T, true>, conv3x3_ws_kernel<T, false>}) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) (void)hipGetLastError();
     }
     attr_done = true;
   }
-  const size_t lds = 3 * (size_t)PIT * 64 * PROW + 2 * 3 * (size_t)128 * 64;
-  static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; } return n; }();
   const int ntp = ((n_mt + 7) / 8) * 8 * n_nt;
   const int grid = ntp < ncu ? ntp : ncu;   // one persistent workgroup per CU
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, n_mt, n_nt);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ws::LDS_BYTES, s, a, n_mt, n_nt);
   return 0;
 }
