@@ -26,10 +26,42 @@ constexpr int VW = 16, TH = 16, PW = VW + 2, PH = TH + 2, NPX = PW * PH;   // 18
 constexpr int PIT = 6, FR = 64, PLANE = PIT * FR * PROW;                    // 36,864 B per patch plane
 constexpr int AROWB = PW * PROW;                                            // bytes between patch rows
 constexpr int BN = 128, WTILE = BN * 64, WIT = 3 * WTILE / (256 * 16);      // 6 x 16 B per loader thread per kernel row
-constexpr size_t LDS_BYTES = 3 * (size_t)PLANE + 2 * 3 * (size_t)WTILE;     // 159,744 B
+constexpr int CBUF = BN * 4;                                                // bias + emb of one tile's channels (f32)
+constexpr size_t LDS_BYTES = 3 * (size_t)PLANE + 2 * 3 * (size_t)WTILE + 2 * CBUF;   // 160,768 B
 }  // namespace ws
 
-template <typename T, bool PRO>
+// GN affine (+ SiLU) of one 16-byte fragment.  bf16: fp32 math on element PAIRS (v_pk_fma/mul/add_f32: two elements per VALU
+// issue; the loaders' VALU stream competes with the consumers' MFMA issue on the same SIMD, so every instruction counts).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 ws_pro_frag(const u32x4& raw, const f32x2 (&a2)[4], const f32x2 (&b2)[4], bool silu, bf16) {
+  u32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t w = raw[i];
+    const f32x2 x = f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+    f32x2 v = a2[i] * x + b2[i];
+    if (silu) {   // v * rcp(1 + exp2(-log2(e) * v)): the same operation sequence as silu_fast<true>
+      const f32x2 sc = v * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+      const f32x2 d = f32x2{__builtin_amdgcn_exp2f(sc[0]), __builtin_amdgcn_exp2f(sc[1])} + f32x2{1.0f, 1.0f};
+      v = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    }
+    const bf16x2_t h = bf16x2_t{(bf16)v[0], (bf16)v[1]};
+    out[i] = __builtin_bit_cast(uint32_t, h);
+  }
+  return out;
+}
+__device__ __forceinline__ u32x4 ws_pro_frag(const u32x4& raw, const f32x2 (&a2)[2], const f32x2 (&b2)[2], bool silu, float) {
+  const f32x4 x = __builtin_bit_cast(f32x4, raw);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = a2[j >> 1][j & 1] * x[j] + b2[j >> 1][j & 1];
+    o[j] = silu ? silu_fast<false>(v) : v;
+  }
+  return __builtin_bit_cast(u32x4, o);
+}
+
+template <typename T, int PRO>   // PRO: 0 = no prologue, 1 = GN affine, 2 = GN affine + SiLU
 __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_mt, int n_nt) {
   using namespace ws;
   using E = Elem<T>;
@@ -38,6 +70,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* pbuf = smem;                 // 3 patch planes
   char* wbuf = smem + 3 * PLANE;     // 2 x (3 weight tiles)
+  char* cbuf = wbuf + 2 * 3 * WTILE; // 2 x accumulator start values (bias + timestep embedding) of a tile's 128 channels
 
   const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,11 +99,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
 
   if (loader) {
     // ================================= LOADER waves =================================
+    switch (p.stagger > 0 ? ((p.stagger >> 2) & 3) : 0) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src1 ? p.src1 : p.src0), 0, p.bytes1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wbytes, 0x00020000);
     const int fq = tid & 3, frow = tid >> 2;
-    const int pro = (!PRO || (p.ablate & 2)) ? 0 : (p.pro_silu ? 2 : 1);
+    const bool pro = PRO && !(p.ablate & 2);
     uint32_t woff[WIT];
 #pragma unroll
     for (int i = 0; i < WIT; ++i) woff[i] = (i * 256 + tid) * 16;
@@ -109,7 +143,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       }
     };
     u32x4 raw[PIT] = {};                                  // fragment u of the chunk that is committed next
-    float pa[V] = {}, pb[V] = {}, pan[V] = {}, pbn[V] = {};   // GN (a, b) of that chunk / of the one after it
+    f32x2 pa[V / 2] = {}, pb[V / 2] = {}, pan[V / 2] = {}, pbn[V / 2] = {};   // GN (a, b) of that chunk / of the one after it, as element pairs
     // Every load below is issued unconditionally (a finished stream keeps re-reading its last valid addresses and the data
     // is never committed): a load under a branch makes the compiler's s_waitcnt bookkeeping assume the shortest queue,
     // i.e. vmcnt(0) at every use, which would drain the whole run-ahead.
@@ -124,27 +158,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         const float* ap = p.pro_a + (size_t)n0_ld * p.Cin + ld_c * CHUNK + fq * V;
         const float* bp = p.pro_b + (size_t)n0_ld * p.Cin + ld_c * CHUNK + fq * V;
 #pragma unroll
-        for (int j = 0; j < V; ++j) { pan[j] = ap[j]; pbn[j] = bp[j]; }
+        for (int j = 0; j < V / 2; ++j) { pan[j] = *reinterpret_cast<const f32x2*>(ap + 2 * j); pbn[j] = *reinterpret_cast<const f32x2*>(bp + 2 * j); }
       }
     };
     auto take_ab = [&]() {
 #pragma unroll
-      for (int j = 0; j < V; ++j) { pa[j] = pan[j]; pb[j] = pbn[j]; }
+      for (int j = 0; j < V / 2; ++j) { pa[j] = pan[j]; pb[j] = pbn[j]; }
     };
     auto commit_frag = [&](auto uc, int plane, uint32_t mask) {
       constexpr int u = decltype(uc)::value;
       u32x4 outv = raw[u];
       if (pro) {
-        float f[V];
-        frag_to_float(raw[u], f, T());
-        if (pro == 2) {
-#pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = silu_fast<FAST>(pa[j] * f[j] + pb[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = pa[j] * f[j] + pb[j];
-        }
-        outv = float_to_frag(f, T());
+        outv = ws_pro_frag(raw[u], pa, pb, PRO == 2, T());
         if (!((mask >> u) & 1u)) outv = u32x4{0u, 0u, 0u, 0u};   // zero padding applies AFTER the prologue
       }
       *reinterpret_cast<u32x4*>(pbuf + plane * PLANE + (frow + u * FR) * PROW + fq * 16) = outv;
@@ -176,6 +201,30 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       }
     };
 
+    // ---- accumulator start values of a tile: 128 channels, 4 per thread of the first half-wave ----
+    f32x4 cv_b = f32x4{0.f, 0.f, 0.f, 0.f}, cv_e = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cst_par = 0;
+    auto cinit_load = [&](int t) {     // loads only (no wait, no branch: see issue_frag), consumed by cinit_commit two intervals later
+      int mt, nt, n0, y0, x0;
+      decode(t, mt, nt);
+      origin(mt, n0, y0, x0);
+      const int co = min(nt * BN + (tid & 31) * 4, p.Cout - 4);   // Cout % 128 == 0 for this kernel; the clamp only guards the address
+      const float* dummy = reinterpret_cast<const float*>(p.w);           // any readable 16 bytes: an absent operand is zeroed at commit
+      cv_b = *reinterpret_cast<const f32x4*>(p.bias ? p.bias + co : dummy);
+      cv_e = *reinterpret_cast<const f32x4*>(p.emb ? p.emb + (size_t)n0 * p.emb_stride + co : dummy);
+    };
+    auto cinit_commit = [&]() {
+      const float fb = p.bias ? 1.0f : 0.0f, fe = p.emb ? 1.0f : 0.0f;
+      if (tid < 32) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (p.bias ? cv_b[j] : 0.0f) + (p.emb ? cv_e[j] : 0.0f);
+        *reinterpret_cast<f32x4*>(cbuf + cst_par * CBUF + tid * 16) = v;
+      }
+      (void)fb; (void)fe;
+      cst_par ^= 1;
+    };
+    cinit_load(t_first);
     STAMP_DECL
     // ---- fill the pipeline: chunk 0 committed, chunk 1 and rows 0, 1 in flight ----
     issue_frag(IC<0>()); issue_frag(IC<1>()); issue_frag(IC<2>()); issue_frag(IC<3>()); issue_frag(IC<4>()); issue_frag(IC<5>());
@@ -191,6 +240,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     commit_frag(IC<4>(), 0, vmask_cm); issue_frag(IC<4>());
     commit_frag(IC<5>(), 0, vmask_cm); issue_frag(IC<5>());
     issue_ab();
+    cinit_commit();
 
     STAMP(0)
     int gcnt = 0, plane = 1;           // next weight buffer parity; plane the NEXT chunk is committed into
@@ -218,6 +268,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
           if (nx_ok) commit_frag(IC<2 * ky + 1>(), plane, vmask_cm);
           issue_frag(IC<2 * ky + 1>());
           if (ky == 2) issue_ab();
+          if (c + 1 == p.nchunks && nx_ok) {   // the next tile's accumulator start values: loaded in the first interval, staged in the last
+            if (ky == 0) cinit_load(t_next);
+            if (ky == 2) cinit_commit();
+          }
           STAMP(2)
           __syncthreads();             // kernel row (t, c, ky) is in LDS; after ky == 2 so is the next chunk's patch
           STAMP(4)
@@ -231,7 +285,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     STAMP_FLUSH
   } else {
     // ================================= CONSUMER waves =================================
-    __builtin_amdgcn_s_setprio(2);     // the MFMA stream goes first when both waves of a SIMD are ready
+    // the MFMA stream goes first when both waves of a SIMD are ready (experiment knob: MI355_CONV_STAGGER = consumer | loader << 2)
+    switch (p.stagger > 0 ? (p.stagger & 3) : 2) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
     const int wave = wave8 - 4;
     const int wm = wave >> 1, wn = wave & 1;   // pixel rows 8*wm .. 8*wm+7 of the tile, channels 64*wn .. 64*wn+63
     const int lr = lane & 15, lq = lane >> 4;
@@ -244,6 +299,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
 
     f32x4 acc[8][NI];
     u32x4 af[2][4], bf[2][4];
+    // bias + timestep embedding of a tile's channels: the accumulators START from it (srcC of the tile's first MFMAs), so the
+    // epilogue has no add.  The loaders stage the 128 values of the NEXT tile in LDS (cbuf) during the current tile's last chunk.
+    f32x4 cin[NI];
+    int cpar = 0;
+    auto read_cinit = [&]() {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) cin[ni] = *reinterpret_cast<const f32x4*>(cbuf + cpar * CBUF + (wn * 64 + ni * 16 + lq * 4) * 4);
+      cpar ^= 1;
+    };
     STAMP_DECL
     // row state of the stream of kernel rows (continuous across chunks and tiles)
     int ky = 0, plane = 0, sel = 0, a_cur = a_base, b_cur = b_base;
@@ -266,7 +330,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       for (int ni = 0; ni < NI; ++ni) bf[buf][ni] = *reinterpret_cast<const u32x4*>(wbuf + b_cur + kx * WTILE + ni * 1024);
     };
     // One half-tap: issue the LDS reads of the NEXT step, then the 16 MFMAs of this one.
-    //   R: row parity inside the unrolled row pair, s = 2 * kx + half, ZERO: first tap of a tile (accumulators start at 0)
+    //   R: row parity inside the unrolled row pair, s = 2 * kx + half, ZERO: first tap of a tile (accumulators start at bias + emb)
     auto step = [&](auto Rc, auto sc, auto zeroc, bool more_rows) {
       constexpr int R = decltype(Rc)::value, s = decltype(sc)::value;
       constexpr bool ZERO = decltype(zeroc)::value != 0;
@@ -291,14 +355,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            if constexpr (ZERO) acc[half * 4 + j][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (ZERO) acc[half * 4 + j][ni] = cin[ni];
             mma16(acc[half * 4 + j][ni], bf[bpar][ni], af[half][j], T());   // D rows = channels, cols = pixels
           }
       } else if constexpr (ZERO) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[half * 4 + j][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int ni = 0; ni < NI; ++ni) acc[half * 4 + j][ni] = cin[ni];
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -312,25 +376,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       int mt, nt, n0, y0, x0;
       decode(t, mt, nt);
       origin(mt, n0, y0, x0);
-      // epilogue operands that do not depend on the pixel: fetched now, used after the last row
       const int co_w = nt * BN + wn * 64 + 4 * lq;
-      f32x4 add4[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int co = co_w + ni * 16;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (co < p.Cout) {
-          if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + co);
-          if (p.emb) {
-            const f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)n0 * p.emb_stride + co);
-            v = f32x4{v[0] + ev[0], v[1] + ev[1], v[2] + ev[2], v[3] + ev[3]};
-          }
-        }
-        add4[ni] = v;
-      }
       for (int r = 0; r < ngr; r += 2) {
         const bool last_pair = r + 2 >= ngr;
-        if (r == 0) { step(IC<0>(), IC<0>(), IC<1>(), true); step(IC<0>(), IC<1>(), IC<1>(), true); }
+        if (r == 0) { read_cinit(); step(IC<0>(), IC<0>(), IC<1>(), true); step(IC<0>(), IC<1>(), IC<1>(), true); }
         else { step(IC<0>(), IC<0>(), IC<0>(), true); step(IC<0>(), IC<1>(), IC<0>(), true); }
         step(IC<0>(), IC<2>(), IC<0>(), true); step(IC<0>(), IC<3>(), IC<0>(), true);
         step(IC<0>(), IC<4>(), IC<0>(), true); step(IC<0>(), IC<5>(), IC<0>(), true);
@@ -369,7 +418,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
           if constexpr (!PAIR) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              f32x4 o = f32x4{acc[mi][ni][0] + add4[ni][0], acc[mi][ni][1] + add4[ni][1], acc[mi][ni][2] + add4[ni][2], acc[mi][ni][3] + add4[ni][3]};
+              f32x4 o = acc[mi][ni];
               if (p.res_mode != RES_NONE) {
                 const f32x4 tt = __builtin_bit_cast(f32x4, rr[j][ni]);
                 o = f32x4{o[0] + tt[0], o[1] + tt[1], o[2] + tt[2], o[3] + tt[3]};
@@ -393,8 +442,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
               bf16x4 ta, tb;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                ta[q] = (bf16)(acc[mi][2 * k][q] + add4[2 * k][q] + ra[q]);
-                tb[q] = (bf16)(acc[mi][2 * k + 1][q] + add4[2 * k + 1][q] + rb[q]);
+                ta[q] = (bf16)(acc[mi][2 * k][q] + ra[q]);
+                tb[q] = (bf16)(acc[mi][2 * k + 1][q] + rb[q]);
               }
               const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
               const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
@@ -425,10 +474,10 @@ int launch_ws(ConvKArgs a, int BM, int BN, int ks, hipStream_t s) {
   const int n_mt = a.N * a.tiles_x * a.tiles_y, n_nt = (a.Cout + 127) / 128;
   static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; } return n; }();
   if (n_mt * n_nt < ncu) return 1;                                    // fewer tiles than CUs: the plain kernel's smaller tiles fill the chip better
-  auto kern = a.pro_a ? conv3x3_ws_kernel<T, true> : conv3x3_ws_kernel<T, false>;
+  auto kern = !a.pro_a ? conv3x3_ws_kernel<T, 0> : (a.pro_silu ? conv3x3_ws_kernel<T, 2> : conv3x3_ws_kernel<T, 1>);
   static bool attr_done = false;
   if (!attr_done) {
-    for (auto k : {conv3x3_ws_kernel<T, true>, conv3x3_ws_kernel<T, false>}) {
+    for (auto k : {conv3x3_ws_kernel<T, 0>, conv3x3_ws_kernel<T, 1>, conv3x3_ws_kernel<T, 2>}) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) (void)hipGetLastError();
     }
