@@ -9,8 +9,8 @@ resident in HBM before the timed region.  Weak scaling: every rank samples its o
 
     python bench.py --gpus N --steps K --warmup W      (N > 1: launched under torch.distributed.run)
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel family = conv_igemm, measured live with
-HIP events around every launch of one forward, on the launch stream) and `cpu_baseline` (the fp32
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = conv3x3_ws_kernel, measured live with
+HIP events around every one of its launches in one forward, on the launch stream) and `cpu_baseline` (the fp32
 PyTorch-CPU oracle timed on the host cores on a bounded sample; rank 0, N = 1 only).
 """
 import argparse
@@ -115,27 +115,39 @@ def main():
         dt = float(tt.item())
     assert out.shape[0] == B * world and out.dtype == torch.uint8
 
-    # ---- roofline of the dominant kernel family (conv_igemm), HIP events around every launch of one forward ----
+    # ---- roofline of the dominant kernel, HIP events around every launch of one forward (on the launch stream) ----
+    # Dominant kernel (rocprofv3 --kernel-trace: ~43 % of GPU time, profiles/): conv3x3_ws_kernel, the warp-specialised persistent
+    # 3x3 implicit-GEMM; mi355_unet_profile reports its launches as tile_m == 256.  Algorithmic FLOPs = 2 * MACs of the conv.
     tt = torch.full((B,), 0.5, device=dev)
     eng.profile(x0, tt)  # warm
     recs = eng.profile(x0, tt)
     conv = [r for r in recs if r["kind"] == "conv"]
+    dom = [r for r in conv if r["tile"][0] == 256] or conv
     by = {}
     for r in recs:
         d = by.setdefault(r["kind"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
         d["ms"] += r["ms"]; d["flops"] += r["flops"]; d["bytes"] += r["bytes"]; d["n"] += 1
     fwd_ms = sum(r["ms"] for r in recs)
-    cms, cfl, cby = by["conv"]["ms"], by["conv"]["flops"], by["conv"]["bytes"]
+    cms, cfl = by["conv"]["ms"], by["conv"]["flops"]
+    dms, dfl, dby = sum(r["ms"] for r in dom), sum(r["flops"] for r in dom), sum(r["bytes"] for r in dom)
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
-    achieved = cfl / (cms * 1e-3) / 1e12
+    achieved = dfl / (dms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(REPO, "profiles", "r1_pmc_hbm_traffic.json")   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
+    if os.path.exists(pmc_file) and a.precision == "bf16" and B == 256:
+        pj = json.load(open(pmc_file))
+        ent = pj.get("kernels", {}).get("conv3x3_ws_kernel")
+        if ent:
+            traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r1_pmc_hbm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
     roofline = {
-        "kernel": "conv_igemm_kernel (all tile variants; %d launches per forward)" % len(conv),
+        "kernel": "conv3x3_ws_kernel<%s> (warp-specialised persistent 3x3 implicit-GEMM; %d of %d conv launches per forward)" % (a.precision, len(dom), len(conv)),
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-        "traffic": None,
-        "avg_launch_us": round(1e3 * cms / len(conv), 2),
-        "flops_per_launch": cfl / len(conv),
-        "hbm_algorithmic_gbs": round(cby / (cms * 1e-3) / 1e9, 1),
-        "share_of_forward": round(cms / fwd_ms, 3),
+        "traffic": traffic, "traffic_source": traffic_src,
+        "avg_launch_us": round(1e3 * dms / len(dom), 2),
+        "flops_per_launch": dfl / len(dom),
+        "algorithmic_bytes_per_launch": dby / len(dom),
+        "share_of_forward": round(dms / fwd_ms, 3),
+        "all_conv_kernels": {"launches": len(conv), "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2), "share_of_forward": round(cms / fwd_ms, 3)},
         "forward_ms_by_kind": {k: round(v["ms"], 3) for k, v in by.items()},
     }
     if a.profile_out and rank == 0:

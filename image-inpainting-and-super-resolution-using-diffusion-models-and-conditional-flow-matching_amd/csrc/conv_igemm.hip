@@ -637,6 +637,11 @@ ConvGeom conv_geometry(const ConvDesc& d) {
   ConvGeom r;
   r.Ho = g.Ho; r.Wo = g.Wo; r.BM = g.BM; r.BN = g.BN; r.lds_bytes = g.lds;
   r.grid_m = g.groups * g.tiles_x * g.tiles_y; r.grid_n = (d.Cout + g.BN - 1) / g.BN;
+  const int CH = d.dtype == 0 ? 16 : 32;
+  if (d.C0 % CH == 0 && d.C1 % CH == 0 &&
+      ws_eligible(d.ks, g.BM, g.BN, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.N, g.Ho, g.Wo, d.Cout)) {
+    r.BM = 256; r.lds_bytes = ws::LDS_BYTES;   // warp-specialised persistent kernel: 16 x 16 pixel tiles (grid_m / grid_n stay the plain launch's: workspace sizing)
+  }
   return r;
 }
 

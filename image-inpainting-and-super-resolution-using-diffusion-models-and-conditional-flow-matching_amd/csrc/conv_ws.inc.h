@@ -462,18 +462,30 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   }
 }
 
+// Shapes the warp-specialised kernel takes (everything else stays on the plain kernel): the plain tile choice already was the
+// largest one (>= 512 workgroups of 128 x 128), 3x3 / stride 1 / NHWC output, an even number of 64-byte channel chunks
+// (row pairs and chunk pairs are unrolled), images of at least one 16 x 16 tile, and at least one tile per CU.
+static int ws_num_cus() {
+  static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; } return n; }();
+  return ncu;
+}
+static bool ws_eligible(int ks, int BM, int BN, int G, int bn_pack, int out_mode, int stride, int nchunks, int N, int Ho, int Wo, int Cout) {
+  static const int enabled = getenv("MI355_CONV_WS") ? atoi(getenv("MI355_CONV_WS")) : 1;
+  if (!enabled || ks != 3 || BM != 128 || BN != 128 || G != 1 || bn_pack != 128 || out_mode != OUT_NHWC) return false;
+  if (stride != 1 || nchunks < 2 || (nchunks & 1)) return false;
+  if (Wo < ws::VW || Ho < ws::TH) return false;
+  const int n_mt = N * ((Wo + ws::VW - 1) / ws::VW) * ((Ho + ws::TH - 1) / ws::TH), n_nt = (Cout + 127) / 128;
+  return n_mt * n_nt >= ws_num_cus();   // fewer tiles than CUs: the plain kernel's smaller tiles fill the chip better
+}
+
 // 0 = launched, 1 = not eligible (caller uses the plain kernel)
 template <typename T>
 int launch_ws(ConvKArgs a, int BM, int BN, int ks, hipStream_t s) {
-  static const int enabled = getenv("MI355_CONV_WS") ? atoi(getenv("MI355_CONV_WS")) : 1;
-  if (!enabled || ks != 3 || BM != 128 || BN != 128 || a.G != 1 || a.bn_pack != 128 || a.out_mode != OUT_NHWC) return 1;
-  if (a.stride != 1 || a.nchunks < 2 || (a.nchunks & 1)) return 1;   // row pairs (consumers) and chunk pairs (loaders) are unrolled
-  if (a.Wo < ws::VW || a.Ho < ws::TH) return 1;                       // 16 x 16 pixel tiles
+  if (!ws_eligible(ks, BM, BN, a.G, a.bn_pack, a.out_mode, a.stride, a.nchunks, a.N, a.Ho, a.Wo, a.Cout)) return 1;
   a.lvw = 4; a.lth = 4; a.PW = ws::PW; a.PH = ws::PH; a.NP = ws::NPX;
   a.tiles_x = (a.Wo + ws::VW - 1) / ws::VW; a.tiles_y = (a.Ho + ws::TH - 1) / ws::TH;
   const int n_mt = a.N * a.tiles_x * a.tiles_y, n_nt = (a.Cout + 127) / 128;
-  static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; } return n; }();
-  if (n_mt * n_nt < ncu) return 1;                                    // fewer tiles than CUs: the plain kernel's smaller tiles fill the chip better
+  const int ncu = ws_num_cus();
   auto kern = !a.pro_a ? conv3x3_ws_kernel<T, 0> : (a.pro_silu ? conv3x3_ws_kernel<T, 2> : conv3x3_ws_kernel<T, 1>);
   static bool attr_done = false;
   if (!attr_done) {
