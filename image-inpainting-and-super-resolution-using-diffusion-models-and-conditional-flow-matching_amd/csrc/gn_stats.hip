@@ -16,6 +16,7 @@ struct GnKArgs {
   int N, HW, groups; float eps;
   const float* gamma; const float* beta; const float* film; int film_stride;
   float* a; float* b;
+  void* y; int y_silu;   // optional: also write silu?(a*x + b) as one NHWC tensor of C0 + C1 channels (small images: see gn_affine_launch)
 };
 
 constexpr int GN_THREADS = 512;
@@ -97,6 +98,32 @@ __global__ void __launch_bounds__(GN_THREADS) gn_affine_kernel(GnKArgs p) {
     }
     p.a[(size_t)n * C + c] = a;
     p.b[(size_t)n * C + c] = b;
+    ch_s[c] = a; ch_q[c] = b;
+  }
+  if (p.y == nullptr) return;
+  // ---- apply pass (small images): the image was just read, so this second read comes from L2 ----
+  __syncthreads();
+  if (prow < ppi) {
+    constexpr bool FAST = Elem<T>::DTYPE == 1;
+    const bool from0 = cb < p.C0;
+    const T* sp = from0 ? reinterpret_cast<const T*>(p.src0) + cb : reinterpret_cast<const T*>(p.src1) + (cb - p.C0);
+    const int Cs = from0 ? p.C0 : p.C1;
+    sp += (size_t)n * p.HW * Cs;
+    T* yp = reinterpret_cast<T*>(p.y) + (size_t)n * p.HW * C + cb;
+    float av[V], bv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { av[j] = ch_s[cb + j]; bv[j] = ch_q[cb + j]; }
+    for (int pix = prow; pix < p.HW; pix += ppi) {
+      const u32x4 r0 = *reinterpret_cast<const u32x4*>(sp + (size_t)pix * Cs);
+      float f[V];
+      frag_to_float(r0, f, T());
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float v = av[j] * f[j] + bv[j];
+        f[j] = p.y_silu ? (FAST ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)) : v / (1.0f + expf(-v))) : v;
+      }
+      *reinterpret_cast<u32x4*>(yp + (size_t)pix * C) = float_to_frag(f, T());
+    }
   }
 }
 
@@ -178,7 +205,7 @@ int gn_affine_launch(const GnDesc& d, hipStream_t stream) {
   MI355_REQUIRE(d.C0 % V == 0 && d.C1 % V == 0, -2, "groupnorm: channels must be a multiple of the 16-byte fragment");
   MI355_REQUIRE(C / V <= GN_THREADS, -4, "groupnorm: too many channels");
   MI355_REQUIRE(d.groups <= GN_THREADS, -4, "groupnorm: too many groups");
-  GnKArgs a{d.src0, d.src1, d.C0, d.C1, d.N, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b};
+  GnKArgs a{d.src0, d.src1, d.C0, d.C1, d.N, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b, d.y, d.y_silu};
   const int ppi = GN_THREADS / (C / V);
   const size_t lds = ((size_t)2 * ppi * C + 2 * C + 2 * d.groups) * sizeof(float);
   if (d.dtype == 0) hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(d.N), dim3(GN_THREADS), lds, stream, a);

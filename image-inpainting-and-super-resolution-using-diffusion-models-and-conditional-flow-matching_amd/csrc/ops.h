@@ -61,6 +61,7 @@ struct GnDesc {
   const float* film = nullptr; int film_stride = 0;  // [N][2C]: scale | shift (use_scale_shift_norm)
   float* a = nullptr;
   float* b = nullptr;
+  void* y = nullptr; int y_silu = 0;   // optional: also write silu?(a*x + b), NHWC [N][HW][C0 + C1] (the consumer conv then has no prologue)
 };
 int gn_affine_launch(const GnDesc& d, hipStream_t stream);
 // out = avgpool2x2(silu?(a * in + b)) on NHWC tensors (a, b per (n, c), may be null): the ResBlock(down=True) input path

@@ -89,12 +89,18 @@ struct Walker {
   }
   const PlanTensor& T(int id) const { return net->tensors[id]; }
 
-  void add_gn(int s0, int s1, const std::string& wname, const std::string& bname, int film_off) {
+  // Returns -1 (the consumer conv applies a*x + b (+SiLU) in its staging prologue) or, for small images, the id of a tensor
+  // that already holds silu?(GN(x)): at 8x8 and below the convs are latency-bound 64-pixel-tile launches whose prologue math
+  // and per-image (a, b) loads sit on the critical path, while the GN kernel has the whole image in L2 anyway.
+  int add_gn(int s0, int s1, const std::string& wname, const std::string& bname, int film_off, int apply_silu, bool may_apply = true) {
+    static const int max_hw = getenv("MI355_GN_APPLY_MAXHW") ? atoi(getenv("MI355_GN_APPLY_MAXHW")) : 64;
     const int C = T(s0).C + (s1 >= 0 ? T(s1).C : 0);
     PlanOp op; op.kind = OP_GN; op.src0 = s0; op.src1 = s1;
     op.gamma_off = put_f32(wname, {C}); op.beta_off = put_f32(bname, {C}); op.film_emb_off = film_off;
+    if (may_apply && T(s0).H * T(s0).W <= max_hw) { op.dst = tensor(C, T(s0).H, T(s0).W); op.pro_silu = apply_silu; }
     net->ops.push_back(op);
     if (C > net->max_gn_c) net->max_gn_c = C;
+    return op.dst;
   }
   // returns dst tensor (or -1 for the NCHW fp32 network output)
   int add_conv(const std::string& prefix, int s0, int s1, int Cin_logical, int Cout, int ks, int mode, bool conv1d, int use_pro,
@@ -123,7 +129,7 @@ struct Walker {
     emb_total += ew;
     P(p + ".emb_layers.1.weight", {ew, 4 * cfg.model_channels});
     P(p + ".emb_layers.1.bias", {ew});
-    add_gn(s0, s1, p + ".in_layers.0.weight", p + ".in_layers.0.bias", -1);
+    const int y1 = add_gn(s0, s1, p + ".in_layers.0.weight", p + ".in_layers.0.bias", -1, 1, !down);
     int h1;
     int res = s0, res_mode = up ? RES_UP2 : RES_SAME;
     if (down) {
@@ -136,9 +142,10 @@ struct Walker {
       h1 = add_conv(p + ".in_layers.2", op.dst, -1, cin, cout, 3, CONV_UNIT, false, 0, 0, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC);
       res = resample(s0, CONV_POOL2);
     } else {
-      h1 = add_conv(p + ".in_layers.2", s0, s1, cin, cout, 3, up ? CONV_UP2 : CONV_UNIT, false, 1, 1, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC);
+      h1 = y1 >= 0 ? add_conv(p + ".in_layers.2", y1, -1, cin, cout, 3, up ? CONV_UP2 : CONV_UNIT, false, 0, 0, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC)
+                   : add_conv(p + ".in_layers.2", s0, s1, cin, cout, 3, up ? CONV_UP2 : CONV_UNIT, false, 1, 1, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC);
     }
-    add_gn(h1, -1, p + ".out_layers.0.weight", p + ".out_layers.0.bias", film ? eoff : -1);
+    const int y2 = add_gn(h1, -1, p + ".out_layers.0.weight", p + ".out_layers.0.bias", film ? eoff : -1, 1);
     if (cin != cout) {
       if (up || down) { err = "ResBlock(up/down) with a channel change is not supported"; return -1; }
       auto it = pidx.find(p + ".skip_connection.weight");
@@ -149,6 +156,7 @@ struct Walker {
       err = "identity skip over a channel concat is not supported";
       return -1;
     }
+    if (y2 >= 0) return add_conv(p + ".out_layers.3", y2, -1, cout, cout, 3, CONV_UNIT, false, 0, 0, -1, res, res_mode, OUT_NHWC);
     return add_conv(p + ".out_layers.3", h1, -1, cout, cout, 3, CONV_UNIT, false, 1, 1, -1, res, res_mode, OUT_NHWC);
   }
 
@@ -156,8 +164,9 @@ struct Walker {
     if (heads <= 0 || C % heads != 0) { err = "attention: bad head count"; return -1; }
     const int ch = C / heads;
     if (ch != 32 && ch != 64 && ch != 128) { err = "attention: head channels must be 32, 64 or 128 (got " + std::to_string(ch) + ")"; return -1; }
-    add_gn(x, -1, p + ".norm.weight", p + ".norm.bias", -1);
-    const int qkv = add_conv(p + ".qkv", x, -1, C, 3 * C, 1, CONV_UNIT, true, 1, 0, -1, -1, RES_NONE, OUT_NHWC);
+    const int yn = add_gn(x, -1, p + ".norm.weight", p + ".norm.bias", -1, 0);
+    const int qkv = yn >= 0 ? add_conv(p + ".qkv", yn, -1, C, 3 * C, 1, CONV_UNIT, true, 0, 0, -1, -1, RES_NONE, OUT_NHWC)
+                            : add_conv(p + ".qkv", x, -1, C, 3 * C, 1, CONV_UNIT, true, 1, 0, -1, -1, RES_NONE, OUT_NHWC);
     PlanOp op; op.kind = OP_ATTN; op.src0 = qkv; op.heads = heads; op.ch = ch;
     op.dst = tensor(C, T(x).H, T(x).W);
     net->ops.push_back(op);
@@ -232,7 +241,7 @@ struct Walker {
       }
     }
     if (!err.empty()) return -1;
-    add_gn(h, -1, "out.0.weight", "out.0.bias", -1);
+    add_gn(h, -1, "out.0.weight", "out.0.bias", -1, 1, false);
     add_conv("out.2", h, -1, input_ch, cfg.out_channels, 3, CONV_UNIT, false, 1, 1, -1, -1, RES_NONE, OUT_NCHW_F32);
     if (!err.empty()) return -1;
     // batched emb_layers: Wt [4mc][emb_total], bias [emb_total]
@@ -437,9 +446,10 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
       if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = estride; }
       g.a = F(l.gna); g.b = F(l.gnb);
+      if (op.dst >= 0) { g.y = TP(op.dst); g.y_silu = op.pro_silu; }
       rc = gn_affine_launch(g, stream);
       r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
-      r.bytes = (double)B * s0.H * s0.W * (s0.C + C1) * esz;
+      r.bytes = (double)B * s0.H * s0.W * (s0.C + C1) * esz * (op.dst >= 0 ? 2 : 1);
     } else if (op.kind == OP_CONV) {
       ConvDesc c; c.dtype = dtype; c.src0 = TP(op.src0); c.C0 = s0.C; c.src1 = TP(op.src1); c.C1 = C1;
       c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks;

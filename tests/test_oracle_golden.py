@@ -107,7 +107,7 @@ def test_updown(golden):
 
 
 UNETS = ["tiny_in1", "tiny_in2", "tiny_in3", "tiny_in6", "tiny_film_updown_neworder", "tiny_noconvresample", "mnist",
-         "cifar", "cifar_in6", "flowers_in6"]
+         "cifar", "cifar_in6", "flowers_in6", "px128_in6"]
 
 
 def unet_shapes(cfg):

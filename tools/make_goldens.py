@@ -201,11 +201,17 @@ UNET_CASES = {
     "flowers_in6": (dict(image_size=64, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=1,
                          attention_resolutions=(4,), channel_mult=(1, 2, 3, 4), num_heads=4, num_head_channels=64,
                          use_scale_shift_norm=True, resblock_updown=True), 1, 1236),
+    # BASELINE cfg 5 geometry (128 px, create_model's 128-px channel_mult (unet.py:68-69), attention at 32/16/8 -> T = 1024/256/64,
+    # in = 6) at a quarter of the width so the fixture and the CPU oracle stay small
+    "px128_in6": (dict(image_size=128, in_channels=6, model_channels=32, out_channels=3, num_res_blocks=1,
+                       attention_resolutions=(4, 8, 16), channel_mult=(1, 1, 2, 3, 4), num_heads=4, num_head_channels=32), 1, 1237),
 }
 
 
 def g_unets():
     for name, (kw, B, seed) in UNET_CASES.items():
+        if os.environ.get("ONLY_UNET") and name != os.environ["ONLY_UNET"]:
+            continue
         net = load_synth(make_unet(**kw), seed)
         x = randn(seed + 50000, B, kw["in_channels"], kw["image_size"], kw["image_size"])
         t = torch.tensor([0.37, 0.91, 0.0, 1.0][:B])
