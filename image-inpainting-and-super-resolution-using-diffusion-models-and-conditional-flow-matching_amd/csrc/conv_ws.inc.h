@@ -40,7 +40,11 @@ __device__ __forceinline__ u32x4 ws_pro_frag(const u32x4& raw, const f32x2 (&a2)
     const uint32_t w = raw[i];
     const f32x2 x = f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
     f32x2 v = a2[i] * x + b2[i];
-    if (silu) {   // v * rcp(1 + exp2(-log2(e) * v)): the same operation sequence as silu_fast<true>
+    if (silu && (WS_ABLATE & 128)) {   // diagnostic only: same instruction count without the two transcendentals
+      const f32x2 sc = v * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+      const f32x2 d = sc * sc + f32x2{1.0f, 1.0f};
+      v = v * (d * sc + d);
+    } else if (silu) {   // v * rcp(1 + exp2(-log2(e) * v)): the same operation sequence as silu_fast<true>
       const f32x2 sc = v * f32x2{-1.4426950408889634f, -1.4426950408889634f};
       const f32x2 d = f32x2{__builtin_amdgcn_exp2f(sc[0]), __builtin_amdgcn_exp2f(sc[1])} + f32x2{1.0f, 1.0f};
       v = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};

@@ -64,6 +64,7 @@ CONV_CASES = [
     (64, 64, 32, 32, 256, 3, 1, 0),   # two channel tiles per pixel tile
     (64, 128, 16, 16, 128, 3, 1, 2),  # nearest x2 gather
     (80, 64, 28, 28, 128, 3, 1, 0),   # ragged tiles, tile count not a multiple of the persistent grid
+    (16, 64, 64, 64, 128, 3, 1, 0),   # 4 x 4 tiles per image (BASELINE cfg 4 / 5 image sizes)
 ]
 
 
