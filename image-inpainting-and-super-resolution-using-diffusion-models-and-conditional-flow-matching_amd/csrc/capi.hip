@@ -232,6 +232,10 @@ int mi355_replace_mask(float* x, const float* cond, const float* z, float pad_va
   return replace_mask_launch(x, cond, z, pad_value, noisy, sa, sb, use_philox, seed, offset, n, S(stream));
 }
 int mi355_clip(float* x, float lo, float hi, int64_t n, void* stream) { return clip_launch(x, lo, hi, n, S(stream)); }
+int mi355_ema_update(float* target, const float* source, float decay, float one_minus_decay, int64_t n, void* stream) {
+  MI355_REQUIRE(target && source, -1, "ema_update: null argument");
+  return ema_update_launch(target, source, decay, one_minus_decay, n, S(stream));
+}
 int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream) { return quantize_u8_launch(x, out, n, S(stream)); }
 int mi355_to_unit_range(const float* x, float* out, int64_t n, void* stream) { return to_unit_range_launch(x, out, n, S(stream)); }
 int mi355_randn(float* out, uint64_t seed, uint64_t offset, int64_t n, void* stream) { return randn_launch(out, seed, offset, n, S(stream)); }

@@ -172,6 +172,19 @@ int clip_launch(float* x, float lo, float hi, int64_t n, hipStream_t s) {
   });
 }
 
+// EMA of a parameter tensor: target = target * decay + source * (1 - decay)  (cifar10/utils_cifar.py:47-53), two separately
+// rounded products like the reference's eager expression (this file is compiled with fp contraction off).
+int ema_update_launch(float* target, const float* source, float decay, float one_minus_decay, int64_t n, hipStream_t s) {
+  return launch_ew4(n, s, [=] __device__(int64_t i, int64_t, int cnt) {
+    float t[4], v[4];
+    ld4(target, i, cnt, t);
+    ld4(source, i, cnt, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = t[j] * decay + v[j] * one_minus_decay;
+    st4(target, i, cnt, t);
+  });
+}
+
 int quantize_u8_launch(const float* x, uint8_t* out, int64_t n, hipStream_t s) {
   return launch_ew4(n, s, [=] __device__(int64_t i, int64_t, int cnt) {
     float a[4];

@@ -91,6 +91,12 @@ class Ops:
         check(_lib.lib().mi355_clip(_req(x, "x"), float(lo), float(hi), x.numel(), _stream()))
         return x
 
+    def ema_update_(self, target, source, decay):
+        """target = target * decay + source * (1 - decay), in place (cifar10/utils_cifar.py:47-53)."""
+        _same(target, source, "target", "source")
+        check(_lib.lib().mi355_ema_update(_req(target, "target"), _req(source, "source"), float(decay), float(1 - decay), target.numel(), _stream()))
+        return target
+
     def quantize_u8(self, x):
         out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
         check(_lib.lib().mi355_quantize_u8(_req(x, "x"), _req(out, "out", torch.uint8), x.numel(), _stream()))

@@ -33,11 +33,17 @@ def generate_samples(model, parallel, savedir, step, net_="normal"):
 
 
 def ema(source, target, decay):
-    """cifar10/utils_cifar.py:47-53 (host-side parameter plumbing, used by the training script)."""
+    """cifar10/utils_cifar.py:47-53.  Device-resident fp32 tensors are updated in place by the fused HIP kernel (one launch per
+    state-dict entry instead of three eager kernels + a copy); anything else (CPU tensors, integer buffers) keeps the reference's
+    eager expression - this is training-side parameter plumbing, not the sampler path."""
     source_dict = source.state_dict()
     target_dict = target.state_dict()
     for key in source_dict.keys():
-        target_dict[key].data.copy_(target_dict[key].data * decay + source_dict[key].data * (1 - decay))
+        t, s = target_dict[key].data, source_dict[key].data
+        if t.is_cuda and s.is_cuda and t.dtype == torch.float32 and s.dtype == torch.float32 and t.is_contiguous() and s.is_contiguous():
+            default_ops.ema_update_(t, s, decay)
+        else:
+            t.copy_(t * decay + s * (1 - decay))
 
 
 def infiniteloop(dataloader):

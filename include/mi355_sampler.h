@@ -195,6 +195,10 @@ int mi355_replace_mask(float* x, const float* cond, const float* z, float pad_va
 
 /* clip(x, lo, hi) in place, NaN-propagating like torch.clip (sampling.py:13-14) */
 int mi355_clip(float* x, float lo, float hi, int64_t n, void* stream);
+/* EMA of one parameter tensor, in place: target = target*decay + source*(1-decay)  (cifar10/utils_cifar.py:47-53, called per
+ * state-dict entry at cifar10/train_cifar10.py:154).  one_minus_decay is passed separately because the reference rounds
+ * (1 - decay) from a Python double. */
+int mi355_ema_update(float* target, const float* source, float decay, float one_minus_decay, int64_t n, void* stream);
 /* (x*127.5+128).clip(0,255).to(uint8)  cifar10/compute_fid.py:87 */
 int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 /* x.clip(-1,1)/2 + 0.5  cifar10/utils_cifar.py:40-41 */

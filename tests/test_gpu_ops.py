@@ -179,3 +179,14 @@ def test_philox_randn_moments(ops):
     assert torch.equal(z, z2)  # counter-based: reproducible
     z3 = ops.randn((1 << 10,), DEV, seed=1234, offset=1 << 10)
     assert torch.equal(z3, z[1 << 10: 1 << 11])  # offset addresses the same stream
+
+
+@pytest.mark.gpu
+def test_ema_update_matches_reference_expression(ops):
+    """utils_cifar.ema (cifar10/utils_cifar.py:47-53): target*decay + source*(1-decay), bit-exact vs the eager fp32 expression."""
+    t = randn(11, 3, 1000, 37)
+    s = randn(12, 3, 1000, 37)
+    for decay in (0.9999, 0.5, 0.0):
+        ref = t * decay + s * (1 - decay)
+        got = ops.ema_update_(t.clone().to(DEV), s.to(DEV), decay).cpu()
+        assert torch.equal(got, ref)
