@@ -246,6 +246,10 @@ int mi355_ema_update(float* target, const float* source, float decay, float one_
   MI355_REQUIRE(target && source, -1, "ema_update: null argument");
   return ema_update_launch(target, source, decay, one_minus_decay, n, S(stream));
 }
+int mi355_mse_per_sample(const float* a, const float* b, float* out, int batch, int64_t elems_per_sample, void* stream) {
+  MI355_REQUIRE(a && b && out, -1, "mse_per_sample: null argument");
+  return mse_per_sample_launch(a, b, out, batch, elems_per_sample, S(stream));
+}
 int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream) { return quantize_u8_launch(x, out, n, S(stream)); }
 int mi355_to_unit_range(const float* x, float* out, int64_t n, void* stream) { return to_unit_range_launch(x, out, n, S(stream)); }
 int mi355_randn(float* out, uint64_t seed, uint64_t offset, int64_t n, void* stream) { return randn_launch(out, seed, offset, n, S(stream)); }

@@ -172,6 +172,26 @@ int clip_launch(float* x, float lo, float hi, int64_t n, hipStream_t s) {
   });
 }
 
+// Per-sample mean squared error, torch.mean((a - b)**2, dim=(1, 2, 3)) of the evaluation loop (AD/experiments/main.py:299):
+// one workgroup per sample, fp32 differences, fp64 accumulation.
+__global__ void __launch_bounds__(256) mse_per_sample_kernel(const float* a, const float* b, float* out, int64_t per) {
+  __shared__ double sh[4];
+  const float* pa = a + (int64_t)blockIdx.x * per;
+  const float* pb = b + (int64_t)blockIdx.x * per;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < per; i += 256) { const float d = pa[i] - pb[i]; acc += (double)d * (double)d; }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)((sh[0] + sh[1] + sh[2] + sh[3]) / (double)per);
+}
+int mse_per_sample_launch(const float* a, const float* b, float* out, int batch, int64_t per, hipStream_t s) {
+  MI355_REQUIRE(batch > 0 && per > 0, -2, "mse_per_sample: empty input");
+  hipLaunchKernelGGL(mse_per_sample_kernel, dim3((unsigned)batch), dim3(256), 0, s, a, b, out, per);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // EMA of a parameter tensor: target = target * decay + source * (1 - decay)  (cifar10/utils_cifar.py:47-53), two separately
 // rounded products like the reference's eager expression (this file is compiled with fp contraction off).
 int ema_update_launch(float* target, const float* source, float decay, float one_minus_decay, int64_t n, hipStream_t s) {

@@ -86,6 +86,7 @@ SIGNATURES = {
     "mi355_replace_mask": (_I, [_VP, _VP, _VP, _F, _I, _F, _F, _I, _U64, _U64, _I64, _VP]),
     "mi355_clip": (_I, [_VP, _F, _F, _I64, _VP]),
     "mi355_ema_update": (_I, [_VP, _VP, _F, _F, _I64, _VP]),
+    "mi355_mse_per_sample": (_I, [_VP, _VP, _VP, C.c_int, _I64, _VP]),
     "mi355_quantize_u8": (_I, [_VP, _VP, _I64, _VP]),
     "mi355_to_unit_range": (_I, [_VP, _VP, _I64, _VP]),
     "mi355_randn": (_I, [_VP, _U64, _U64, _I64, _VP]),

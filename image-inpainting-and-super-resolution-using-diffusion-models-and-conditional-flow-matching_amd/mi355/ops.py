@@ -97,6 +97,13 @@ class Ops:
         check(_lib.lib().mi355_ema_update(_req(target, "target"), _req(source, "source"), float(decay), float(1 - decay), target.numel(), _stream()))
         return target
 
+    def mse_per_sample(self, a, b):
+        """torch.mean((a - b)**2, dim=(1, 2, 3))  (AD/experiments/main.py:299)."""
+        _same(a, b, "a", "b")
+        out = torch.empty(a.shape[0], device=a.device, dtype=torch.float32)
+        check(_lib.lib().mi355_mse_per_sample(_req(a, "a"), _req(b, "b"), _req(out, "out"), a.shape[0], a[0].numel(), _stream()))
+        return out
+
     def quantize_u8(self, x):
         out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
         check(_lib.lib().mi355_quantize_u8(_req(x, "x"), _req(out, "out", torch.uint8), x.numel(), _stream()))

@@ -199,6 +199,9 @@ int mi355_clip(float* x, float lo, float hi, int64_t n, void* stream);
  * state-dict entry at cifar10/train_cifar10.py:154).  one_minus_decay is passed separately because the reference rounds
  * (1 - decay) from a Python double. */
 int mi355_ema_update(float* target, const float* source, float decay, float one_minus_decay, int64_t n, void* stream);
+/* out[n] = mean over (C,H,W) of (a - b)^2: the per-sample MSE metric of the evaluation loop
+ * (AD/experiments/main.py:299 `torch.mean((x0 - batch)**2, dim=(1, 2, 3))`) */
+int mi355_mse_per_sample(const float* a, const float* b, float* out, int batch, int64_t elems_per_sample, void* stream);
 /* (x*127.5+128).clip(0,255).to(uint8)  cifar10/compute_fid.py:87 */
 int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 /* x.clip(-1,1)/2 + 0.5  cifar10/utils_cifar.py:40-41 */

@@ -264,3 +264,36 @@ def test_dopri5_vs_oracle():
     torch.testing.assert_close(cg.cpu(), con * torch.e, rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(cg.cpu(), cr, rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(xg.cpu(), xr, rtol=2e-3, atol=2e-3)
+
+
+def test_evaluation_harness_results_json(tmp_path):
+    """Evaluation loop of AD/experiments/main.py:271-314 on the HIP sampler: results.json keys / values, image dumps."""
+    import json
+
+    import evaluation
+    from image_diffusion import sampling
+    from image_diffusion.conditioning import Amortized
+    from image_diffusion.likelihoods import InPainting
+    from image_diffusion.sde_diffusion import DDPM
+
+    ddpm = DDPM(25)
+    lik = InPainting(patch_size=4, pad_value=-2)   # 16-px images: the reference draws the corner from randint(5, 16 - patch - 5)
+    _, net2, _ = _tiny(2, 1, 1002, "fp32")
+    fn = sampling.get_conditional_sample_fn(sampling.make_eps_model(net2, ddpm), ddpm, Amortized(0.9, 0, 0.1), lik)
+    seen = []
+
+    def recording(xT, cond):
+        x0 = fn(xT, cond)
+        seen.append(x0.clone())
+        return x0
+
+    torch.manual_seed(3)
+    batches = [rand_uniform(70 + k, -1.0, 1.0, 3, 1, 16, 16).to(DEV) for k in range(2)]
+    res = evaluation.evaluate(recording, lik, batches, tmp_path, lpips_fn=lambda a, b: (a - b).abs().mean(dim=(1, 2, 3), keepdim=True))
+    ref_mse = torch.cat([torch.mean((x0 - b) ** 2, dim=(1, 2, 3)) for x0, b in zip(seen, batches)]).cpu()
+    assert list(res.keys()) == ["mse_mean", "lpips_mean", "mse_median", "lpips_median", "mse_std", "lpips_std", "fid"]
+    assert abs(res["mse_mean"] - ref_mse.mean().item()) < 1e-6 and abs(res["mse_median"] - ref_mse.median().item()) < 1e-6
+    assert abs(res["mse_std"] - ref_mse.std().item()) < 1e-6 and res["fid"] is None
+    assert json.load(open(tmp_path / "results.json")) == res
+    assert len(list((tmp_path / "generated").glob("image_*.png"))) == 6
+    assert len(list((tmp_path / "generated_groundtruth").glob("image_gt*.png"))) == 12
