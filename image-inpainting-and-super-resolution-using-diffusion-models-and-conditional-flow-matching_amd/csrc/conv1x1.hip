@@ -156,7 +156,25 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // epilogue operands of this output-channel tile are fetched NOW (bias) / before the last group (residual), so their
+    // global-memory latency hides behind the K loop instead of stalling every tile's epilogue
+    constexpr bool PAIR = E::DTYPE == 1;
+    constexpr int NP2 = PAIR ? NI / 2 : NI, PSTEP = PAIR ? 32 : 16;
+    const int co_t = (nt0 + nti) * BN + wn * WTN;
+    const int co_w = co_t + 4 * lq;
+    const int co_s = PAIR ? co_t + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;
+    f32x4 bias4[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bias4[ni] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co_w + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 rr[MI][NP2];
     for (int g = 0; g < ngroups; ++g, ++gi) {
+      if (g == ngroups - 1 && p.res) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int k = 0; k < NP2; ++k)
+            rr[mi][k] = bload16(rsr, ovalid[mi] ? (opix[mi] * (uint32_t)p.Cout + co_s + k * PSTEP) * ESZ : p.obytes, 0);
+      }
       char* wb = wlds + (gi & 1) * (3 * WTILE);
 #pragma unroll
       for (int i = 0; i < WIT; ++i) *reinterpret_cast<u32x4*>(wb + (i * NT1 + tid) * 16) = wreg[i];
@@ -179,24 +197,8 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
         }
       }
     }
-    // ---- epilogue of this output-channel tile: loads first, then 16-byte stores (bf16: tile pairs via permlane16_swap) ----
+    // ---- epilogue of this output-channel tile: 16-byte stores (bf16: tile pairs via permlane16_swap) ----
     {
-      constexpr bool PAIR = E::DTYPE == 1;
-      const int co_t = (nt0 + nti) * BN + wn * WTN;
-      const int co_w = co_t + 4 * lq;
-      const int co_s = PAIR ? co_t + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;
-      constexpr int NP2 = PAIR ? NI / 2 : NI, PSTEP = PAIR ? 32 : 16;
-      u32x4 rr[MI][NP2];
-      if (p.res) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int k = 0; k < NP2; ++k)
-            rr[mi][k] = bload16(rsr, ovalid[mi] ? (opix[mi] * (uint32_t)p.Cout + co_s + k * PSTEP) * ESZ : p.obytes, 0);
-      }
-      f32x4 bias4[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bias4[ni] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co_w + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         f32x4 ad[NI];
