@@ -122,6 +122,11 @@ def lib():
             raise MI355BackendError(
                 f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "This package has no CPU or PyTorch fallback.")
+        # PyTorch-ROCm ships its own libamdhip64; the process must use ONE HIP runtime for the device pointers and streams torch
+        # hands over to mean anything, so torch's copy has to be resident before this library's dependency is resolved
+        # (loading the system runtime first and torch afterwards ends in "no ROCm-capable device is detected").
+        import torch  # noqa: F401
+
         try:
             L = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
