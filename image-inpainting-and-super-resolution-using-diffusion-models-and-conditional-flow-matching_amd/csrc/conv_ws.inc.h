@@ -303,6 +303,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
 
     f32x4 acc[8][NI];
     u32x4 af[2][4], bf[2][4];
+    typedef float f32x16_t __attribute__((ext_vector_type(16)));
+    f32x16_t accb[8];   // WS_ABLATE & 256 only
     // bias + timestep embedding of a tile's channels: the accumulators START from it (srcC of the tile's first MFMAs), so the
     // epilogue has no add.  The loaders stage the 128 values of the NEXT tile in LDS (cbuf) during the current tile's last chunk.
     f32x4 cin[NI];
@@ -354,7 +356,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!(WS_ABLATE & 4)) {
+      if constexpr ((WS_ABLATE & 256) != 0 && Elem<T>::DTYPE == 1) {
+        // timing experiment: the same fragment traffic feeding half as many v_mfma_f32_32x32x16_bf16 (8 per step, 32 cycles each,
+        // holding the issue port 8 of 32 cycles instead of 8 of 16); the numbers produced are meaningless
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            if constexpr (ZERO) accb[half * 4 + j] = f32x16_t{};
+            accb[half * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[bpar][2 * h2]), __builtin_bit_cast(bf16x8, af[half][j]), accb[half * 4 + j], 0, 0, 0);
+          }
+      } else if constexpr (!(WS_ABLATE & 4)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -390,6 +402,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         step(IC<1>(), IC<0>(), IC<0>(), true); step(IC<1>(), IC<1>(), IC<0>(), true);
         step(IC<1>(), IC<2>(), IC<0>(), true); step(IC<1>(), IC<3>(), IC<0>(), true);
         step(IC<1>(), IC<4>(), IC<0>(), true); step(IC<1>(), IC<5>(), IC<0>(), !last_pair || t_next < ntp);
+      }
+      if constexpr ((WS_ABLATE & 256) != 0) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{accb[mi][4 * ni], accb[mi][4 * ni + 1], accb[mi][4 * ni + 2], accb[mi][4 * ni + 3]};
       }
       STAMP(6)
       // ---- epilogue: MFMA rows are channels and columns are pixels, so lane (lr, lq) holds 4 consecutive channels of
