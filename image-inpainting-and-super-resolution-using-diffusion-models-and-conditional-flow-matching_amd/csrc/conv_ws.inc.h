@@ -10,9 +10,9 @@
 //     CONSUMERS (LDS -> MFMA -> epilogue), 128 pixels x 64 channels each.  Every SIMD hosts one of each;
 //   * persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ...; the loaders treat the whole walk as ONE stream of
 //     (tile, chunk, kernel row) items and run ahead of the consumers across tile boundaries:
-//        global loads  : patch fragments and GN (a, b) 1 chunk (3 rows) ahead, weight rows 2 rows ahead (register rings)
-//        LDS commits   : patch chunk q+1 is transformed and written (two fragments per kernel row) while the consumers
-//                        multiply chunk q (3 patch planes); weight row g+1 while they multiply row g (2 buffers)
+//        global loads  : patch fragments and GN (a, b) one chunk (3 rows) ahead in a register ring
+//        LDS commits   : two patch fragments per kernel row, transformed and written one chunk ahead of the consumers
+//                        (2 patch planes); weight rows go global -> LDS by DMA one row ahead (3 row buffers)
 //     ONE workgroup barrier per kernel row;
 //   * the consumers run a register-double-buffered pipeline of half-taps (16 MFMAs each): the LDS reads of step s+1 are
 //     issued before the MFMAs of step s, and the barrier of the next row sits between the last reads and the last
@@ -27,7 +27,8 @@ constexpr int PIT = 6, FR = 64, PLANE = PIT * FR * PROW;                    // 3
 constexpr int AROWB = PW * PROW;                                            // bytes between patch rows
 constexpr int BN = 128, WTILE = BN * 64, WIT = 3 * WTILE / (256 * 16);      // 6 x 16 B per loader thread per kernel row
 constexpr int CBUF = BN * 4;                                                // bias + emb of one tile's channels (f32)
-constexpr size_t LDS_BYTES = 3 * (size_t)PLANE + 2 * 3 * (size_t)WTILE + 2 * CBUF;   // 160,768 B
+constexpr int NPLANES = 2, NWBUF = 3;                                        // patch planes / weight row buffers
+constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE + 2 * CBUF;   // 148,480 B
 }  // namespace ws
 
 // GN affine (+ SiLU) of one 16-byte fragment.  bf16: fp32 math on element PAIRS (v_pk_fma/mul/add_f32: two elements per VALU
@@ -72,9 +73,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   constexpr int V = E::VEC, CHUNK = E::CHUNK, ESZ = sizeof(T);
   constexpr bool FAST = (E::DTYPE == 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* pbuf = smem;                 // 3 patch planes
-  char* wbuf = smem + 3 * PLANE;     // 2 x (3 weight tiles)
-  char* cbuf = wbuf + 2 * 3 * WTILE; // 2 x accumulator start values (bias + timestep embedding) of a tile's 128 channels
+  char* pbuf = smem;                       // NPLANES patch planes
+  char* wbuf = smem + NPLANES * PLANE;     // NWBUF x (3 weight tiles of one kernel row)
+  char* cbuf = wbuf + NWBUF * 3 * WTILE; // 2 x accumulator start values (bias + timestep embedding) of a tile's 128 channels
 
   const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -179,30 +180,37 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       *reinterpret_cast<u32x4*>(pbuf + plane * PLANE + (frow + u * FR) * PROW + fq * 16) = outv;
     };
 
-    // ---- weight stream: 2 kernel rows ahead of the row being committed ----
-    int wl_t = t_first, wl_row = 0, wl_nt;
+    // ---- weight stream: one kernel row ahead, moved by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, no
+    //      ds_write; lane l of a wave lands at M0 base + 16 l, probed in tools/probe/lds_dma_probe.cpp).  The host packer
+    //      stores weights already in their LDS image, so a row (3 taps x 8 KB) is 6 linear 1-KB pieces per wave. ----
+    int wl_t = t_first, wl_row = 0, wl_nt, wl_buf = 0;
     { int mt; decode(wl_t, mt, wl_nt); }
-    u32x4 wreg[2][WIT] = {};
-    auto prefetch_w = [&](auto slotc) {
-      constexpr int slot = decltype(slotc)::value;
+    auto dma_w = [&]() {               // next row of the stream -> wbuf[wl_buf]
       const uint32_t so = ((uint32_t)wl_nt * p.nchunks * 9 + (uint32_t)wl_row * 3) * WTILE;
       if constexpr (!(WS_ABLATE & 8)) {
+        char* dst = wbuf + wl_buf * (3 * WTILE) + wave8 * 1024;
 #pragma unroll
-        for (int i = 0; i < WIT; ++i) wreg[slot][i] = buf_load16(rsw, woff[i], so);
+        for (int i = 0; i < WIT; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, woff[i], so, 0, 0);
       }
+      wl_buf = wl_buf == NWBUF - 1 ? 0 : wl_buf + 1;
       if (++wl_row == ngr) {
         wl_row = 0;
         wl_t = next_valid(wl_t);
         if (wl_t < ntp) { int mt; decode(wl_t, mt, wl_nt); }
       }
     };
-    auto commit_w = [&](auto slotc, int buf) {
-      constexpr int slot = decltype(slotc)::value;
-      char* dst = wbuf + buf * (3 * WTILE) + tid * 16;
-      if constexpr (!(WS_ABLATE & 64)) {
-#pragma unroll
-        for (int i = 0; i < WIT; ++i) *reinterpret_cast<u32x4*>(dst + i * 256 * 16) = wreg[slot][i];
-      }
+    // All but the 8 youngest vector-memory operations of this wave are complete: at the end of an interval those 8 are the
+    // interval's two patch-fragment loads and the 6 DMA pieces of the NEXT row, so the row published by the coming barrier
+    // (DMA issued one interval ago) has landed while nothing younger is waited for.  (gfx9 s_waitcnt: vmcnt[3:0] | expcnt<<4 | lgkmcnt<<8 | vmcnt[5:4]<<14)
+    // Together with the wave's own LDS writes (lgkmcnt 0) this is all the coming barrier has to order, so the loaders use the bare
+    // s_barrier: __syncthreads()'s workgroup release fence would drain vmcnt to 0 (the DMA counts as an LDS write), i.e. wait for
+    // the next row's DMA and the next chunk's patch fragments at every kernel row.
+    auto publish_row = [&]() {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(8 | (7 << 4) | (0 << 8));   // vmcnt(8) lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     };
 
     // ---- accumulator start values of a tile: 128 channels, 4 per thread of the first half-wave ----
@@ -230,62 +238,72 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     };
     cinit_load(t_first);
     STAMP_DECL
-    // ---- fill the pipeline: chunk 0 committed, chunk 1 and rows 0, 1 in flight ----
+    // ---- fill the pipeline: fragments 0-3 of chunk 0 committed, 4-5 still in registers, chunk 1 and row 0 in flight ----
     issue_frag(IC<0>()); issue_frag(IC<1>()); issue_frag(IC<2>()); issue_frag(IC<3>()); issue_frag(IC<4>()); issue_frag(IC<5>());
     issue_ab();
-    prefetch_w(IC<0>()); prefetch_w(IC<1>());
+    dma_w();                           // row 0
     uint32_t vmask_cm = vmask_ld;      // chunks 0 and 1 belong to the first tile (nchunks >= 2)
     take_ab();
-    ld_advance();
+    ld_advance();                      // -> chunk 1
+    issue_ab();
     commit_frag(IC<0>(), 0, vmask_cm); issue_frag(IC<0>());
     commit_frag(IC<1>(), 0, vmask_cm); issue_frag(IC<1>());
     commit_frag(IC<2>(), 0, vmask_cm); issue_frag(IC<2>());
     commit_frag(IC<3>(), 0, vmask_cm); issue_frag(IC<3>());
-    commit_frag(IC<4>(), 0, vmask_cm); issue_frag(IC<4>());
-    commit_frag(IC<5>(), 0, vmask_cm); issue_frag(IC<5>());
-    issue_ab();
     cinit_commit();
 
     STAMP(0)
-    int gcnt = 0, plane = 1;           // next weight buffer parity; plane the NEXT chunk is committed into
+    int plane = 0;                     // plane of the chunk the consumers multiply during this body
     for (int t = t_first; t < ntp;) {
       const int t_next = next_valid(t);
-      // one chunk of the consumer stream: its three weight rows + the commit of the chunk AFTER it (whose fragments were
-      // loaded one chunk ago; each is replaced by the same fragment of the chunk after that as soon as it is committed)
-      auto body = [&](int c, auto cpc) {
-        constexpr int CP = decltype(cpc)::value;   // chunk parity: weight register slot of row (c, ky) = (3 * CP + ky) & 1
+      // One chunk (t, c) of the consumer stream = three intervals, each ending in the barrier that publishes one kernel row:
+      //   ky = 0: the last two fragments of chunk c itself (its plane was still being read one chunk ago until now)
+      //   ky = 1, 2: fragments 0-3 of the chunk AFTER c into the other plane (free since the barrier that ended ky = 0)
+      // every committed fragment's registers are refilled at once with the same fragment of the following chunk, and every
+      // interval queues the DMA of the next kernel row behind its fragment loads.
+      auto body = [&](int c) {
         bool nx_ok = true;
-        if (c + 1 == p.nchunks) {      // the next chunk opens the next tile; the load stream is at that chunk
+        auto tail = [&]() {
+          dma_w();
+          STAMP(3)
+          publish_row();               // kernel row (t, c, ky) and its patch are in LDS
+          STAMP(4)
+        };
+        // ---- ky = 0 ----
+        cinit_load(t_next < ntp ? t_next : t);   // next tile's accumulator start values (tiny, L2-resident; loaded every chunk so that no load sits under a branch)
+        commit_frag(IC<4>(), plane, vmask_cm); issue_frag(IC<4>());
+        commit_frag(IC<5>(), plane, vmask_cm); issue_frag(IC<5>());
+        STAMP(2)
+        tail();
+        // ---- switch to the next chunk ----
+        if (c + 1 == p.nchunks) {      // it opens the next tile; the load stream is at that chunk (its geometry is current)
           nx_ok = t_next < ntp;
           vmask_cm = vmask_ld;
         }
         take_ab();
-        ld_advance();                  // -> the chunk after the one committed below
-        auto interval = [&](auto kyc) {
-          constexpr int ky = decltype(kyc)::value, slot = (3 * CP + ky) & 1;
-          commit_w(IC<slot>(), gcnt & 1); ++gcnt;
-          STAMP(1)
-          prefetch_w(IC<slot>());
-          STAMP(3)
-          if (nx_ok) commit_frag(IC<2 * ky>(), plane, vmask_cm);
-          issue_frag(IC<2 * ky>());
-          if (nx_ok) commit_frag(IC<2 * ky + 1>(), plane, vmask_cm);
-          issue_frag(IC<2 * ky + 1>());
-          if (ky == 2) issue_ab();
-          if (c + 1 == p.nchunks && nx_ok) {   // the next tile's accumulator start values: loaded in the first interval, staged in the last
-            if (ky == 0) cinit_load(t_next);
-            if (ky == 2) cinit_commit();
-          }
-          STAMP(2)
-          __syncthreads();             // kernel row (t, c, ky) is in LDS; after ky == 2 so is the next chunk's patch
-          STAMP(4)
-        };
-        interval(IC<0>()); interval(IC<1>()); interval(IC<2>());
-        plane = plane == 2 ? 0 : plane + 1;
+        ld_advance();                  // -> the chunk after the next one
+        issue_ab();
+        plane ^= 1;
+        // ---- ky = 1 ----
+        if (nx_ok) commit_frag(IC<0>(), plane, vmask_cm);
+        issue_frag(IC<0>());
+        if (nx_ok) commit_frag(IC<1>(), plane, vmask_cm);
+        issue_frag(IC<1>());
+        STAMP(2)
+        tail();
+        // ---- ky = 2 ----
+        if (nx_ok) commit_frag(IC<2>(), plane, vmask_cm);
+        issue_frag(IC<2>());
+        if (nx_ok) commit_frag(IC<3>(), plane, vmask_cm);
+        issue_frag(IC<3>());
+        if (c + 1 == p.nchunks && nx_ok) cinit_commit();
+        STAMP(2)
+        tail();
       };
-      for (int c = 0; c < p.nchunks; c += 2) { body(c, IC<0>()); body(c + 1, IC<1>()); }
+      for (int c = 0; c < p.nchunks; c += 2) { body(c); body(c + 1); }   // nchunks is even (launcher); two chunks per trip keep the in-flight fragment registers free of loop-carried copies
       t = t_next;
     }
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // no DMA piece may still be in flight towards LDS when the workgroup retires
     STAMP_FLUSH
   } else {
     // ================================= CONSUMER waves =================================
@@ -318,8 +336,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     // row state of the stream of kernel rows (continuous across chunks and tiles)
     int ky = 0, plane = 0, sel = 0, a_cur = a_base, b_cur = b_base;
     auto advance_row = [&]() {
-      sel ^= 1;
-      if (++ky == 3) { ky = 0; plane = plane == 2 ? 0 : plane + 1; }
+      sel = sel == NWBUF - 1 ? 0 : sel + 1;
+      if (++ky == 3) { ky = 0; plane ^= 1; }
       a_cur = a_base + plane * PLANE + ky * AROWB;
       b_cur = b_base + sel * (3 * WTILE);
     };
