@@ -335,6 +335,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     STAMP_DECL
     // row state of the stream of kernel rows (continuous across chunks and tiles)
     int ky = 0, plane = 0, sel = 0, a_cur = a_base, b_cur = b_base;
+    const bool gate512 = p.N > 0;   // always true, opaque to the compiler (WS_ABLATE & 512)
     auto advance_row = [&]() {
       sel = sel == NWBUF - 1 ? 0 : sel + 1;
       if (++ky == 3) { ky = 0; plane ^= 1; }
@@ -344,12 +345,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     auto read_a = [&](auto bufc, auto halfc, auto kxc) {
       constexpr int buf = decltype(bufc)::value, half = decltype(halfc)::value, kx = decltype(kxc)::value;
       if constexpr (WS_ABLATE & 4) return;
+      if constexpr (WS_ABLATE & 512) { if (gate512) return; }   // timing experiment: MFMAs on stale fragments, no LDS reads
 #pragma unroll
       for (int j = 0; j < 4; ++j) af[buf][j] = *reinterpret_cast<const u32x4*>(pbuf + a_cur + (half * 4 + j) * AROWB + kx * PROW);
     };
     auto read_b = [&](auto bufc, auto kxc) {
       constexpr int buf = decltype(bufc)::value, kx = decltype(kxc)::value;
       if constexpr (WS_ABLATE & 4) return;
+      if constexpr (WS_ABLATE & 512) { if (gate512) return; }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) bf[buf][ni] = *reinterpret_cast<const u32x4*>(wbuf + b_cur + kx * WTILE + ni * 1024);
     };
