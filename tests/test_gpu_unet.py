@@ -297,3 +297,60 @@ def test_evaluation_harness_results_json(tmp_path):
     assert json.load(open(tmp_path / "results.json")) == res
     assert len(list((tmp_path / "generated").glob("image_*.png"))) == 6
     assert len(list((tmp_path / "generated_groundtruth").glob("image_gt*.png"))) == 12
+
+
+def test_cfg3_cifar_inpainting_amortized_ddpm_ns50_vs_oracle():
+    """BASELINE config 3 at a CPU-feasible batch: CIFAR U-Net with in_channels = 6 (x || condition), centred 16x16 patch = -2,
+    Amortized conditional DDPM ancestral sampler at Ns = 50 with injected noise; fp32 engine vs the fp32 CPU oracle."""
+    from image_diffusion import sampling
+    from image_diffusion.conditioning import Amortized
+    from image_diffusion.likelihoods import InPainting
+    from image_diffusion.sde_diffusion import DDPM
+    from image_diffusion.unet import UNetModel, param_shapes
+
+    Ns, B = 50, 2
+    cfg = unet_ref.UNetConfig(32, 6, 128, 3, 2, (2,), channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
+    net = UNetModel(image_size=32, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+                    channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64, precision="fp32")
+    sd = synth_state_dict(param_shapes(net), 1235)
+    net.load_state_dict(sd)
+    net.to(DEV)
+    ddpm = DDPM(Ns)
+    xT = randn(900, B, 3, 32, 32)
+    cond = rand_uniform(901, -1.0, 1.0, B, 3, 32, 32)
+    cond[:, :, 8:24, 8:24] = -2.0
+    zs = [randn(1000 + j, B, 3, 32, 32) for j in range(Ns - 1)]
+    it = iter(zs)
+    ref = ddpm_ref.amortized_sample(ddpm_ref.make_eps_model(lambda x, t: unet_ref.unet_forward(sd, cfg, x, t), Ns), Ns, xT, cond,
+                                    lambda shape: next(it))
+    with sampling.injected_noise(zs):
+        fn = sampling.get_conditional_sample_fn(sampling.make_eps_model(net, ddpm), ddpm, Amortized(0.9, 0, 0.1), InPainting(16, -2))
+        got = fn(xT.to(DEV), cond.to(DEV))
+    torch.testing.assert_close(got.cpu(), ref, rtol=5e-3, atol=3e-3)   # 50 sequential fp32 U-Net calls through the x0 predictor
+
+
+def test_cfg4_flowers64_superres_cfm_euler_vs_oracle():
+    """BASELINE config 4 at a CPU-feasible size: Flowers-64 U-Net (FiLM, resblock up/down), in = 6 = x || bilinearly upsampled
+    16x16 low-res image (the SuperRes convention of utils_mnist_hy), CFM Euler steps; fp32 engine vs the fp32 CPU oracle."""
+    import torch.nn.functional as F
+
+    from image_diffusion.unet import UNetModel, param_shapes
+
+    steps, B = 4, 1
+    kw = dict(image_size=64, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(4,),
+              channel_mult=(1, 2, 3, 4), num_heads=4, num_head_channels=64, use_scale_shift_norm=True, resblock_updown=True)
+    cfg = unet_ref.UNetConfig(64, 6, 128, 3, 1, (4,), channel_mult=(1, 2, 3, 4), num_heads=4, num_head_channels=64,
+                              use_scale_shift_norm=True, resblock_updown=True)
+    net = UNetModel(precision="fp32", **kw)
+    sd = synth_state_dict(param_shapes(net), 1236)
+    net.load_state_dict(sd)
+    net.to(DEV)
+    x0 = randn(910, B, 3, 64, 64)
+    low = rand_uniform(911, -1.0, 1.0, B, 3, 16, 16)
+    up = F.interpolate(low, (64, 64), mode="bilinear")
+    ts = torch.linspace(0, 1, steps + 1)
+    ref = cfm_ref.euler_trajectory(lambda t, x: unet_ref.unet_forward(sd, cfg, torch.cat((x, up), dim=1), t.repeat(x.shape[0])), x0, ts,
+                                   keep_all=False)
+    x = x0.to(DEV).clone()
+    net.engine(DEV).cfm_euler(x, ts.tolist(), cond=up.to(DEV).contiguous())
+    torch.testing.assert_close(x.cpu(), ref, rtol=2e-3, atol=5e-4)
