@@ -70,4 +70,7 @@ def all_gather_batch(shard: torch.Tensor, total: int) -> torch.Tensor:
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])   # RCCL: pin the barrier's all-reduce to this rank's GPU
+        else:
+            dist.barrier()
