@@ -1,21 +1,23 @@
-"""Counterpart of `AD/image_diffusion/likelihoods.py:12-158`: builders of the condition tensor.
+"""Condition builders (the role of `AD/image_diffusion/likelihoods.py:12-158`): in-painting / out-painting masks with the -2
+sentinel and the bilinear down-then-up "hyper-resolution" degradation.
 
-These run once per batch on the host side of the sampler (the reference loops over images in
-Python); they only index / fill / resize tensors with PyTorch and never touch the per-step path.
+They run once per batch, outside the per-step path, and only index / fill / resize tensors.  The reference draws one patch
+position per image in a Python loop (`Likelihood.sample`, :22-27) - reproduced, because the draw order fixes the RNG stream.
 """
-from typing import Type
+from typing import Callable, Dict, Type
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 
 
-class Likelihood:
-    def sample(self, x: torch.Tensor) -> torch.Tensor:
-        # likelihoods.py:29-34: one independent draw per image
-        return torch.cat([self._sample(x[[k]]) for k in range(x.shape[0])], dim=0)
+def _bilinear(x, size):
+    return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
 
-    def _sample(self, x):
+
+class Likelihood:
+    """`sample(batch)` -> condition tensor; `none_like(x)` -> the "no condition" tensor; `loss(x, condition)` -> data term."""
+
+    def _sample(self, one_image):
         raise NotImplementedError
 
     def none_like(self, x):
@@ -24,79 +26,93 @@ class Likelihood:
     def loss(self, x, condition):
         raise NotImplementedError
 
+    def sample(self, x: torch.Tensor) -> torch.Tensor:
+        rows = []
+        for k in range(x.shape[0]):          # one independent draw per image, in batch order
+            rows.append(self._sample(x[k:k + 1]))
+        return torch.cat(rows, dim=0)
+
 
 class Painting(Likelihood):
+    """Square patch of side `patch_size`; `pad_value` marks unknown pixels."""
+
+    def __init__(self, patch_size: int, pad_value: float):
+        self.patch_size = patch_size
+        self.pad_value = pad_value
+
     @classmethod
     def from_configdict(cls, config):
         return cls(patch_size=config["patch_size"], pad_value=config["pad_value"])
 
-    def __init__(self, patch_size: int, pad_value: float):
-        self.pad_value, self.patch_size = pad_value, patch_size
-
     def get_random_patch(self, image_size):
-        # likelihoods.py:49-53: keep 5 px from the border
-        h = torch.randint(5, image_size - self.patch_size - 5, size=())
-        w = torch.randint(5, image_size - self.patch_size - 5, size=())
-        return h, w
+        """Top-left corner, at least 5 px from every border (:49-53); two scalar draws, row first."""
+        hi = image_size - self.patch_size - 5
+        return torch.randint(5, hi, size=()), torch.randint(5, hi, size=())
+
+    def _window(self, images):
+        top, left = self.get_random_patch(images.shape[-1])
+        return slice(int(top), int(top) + self.patch_size), slice(int(left), int(left) + self.patch_size)
 
     def none_like(self, x):
-        return torch.ones_like(x) * self.pad_value
+        return torch.full_like(x, self.pad_value)
+
+    def _known(self, condition):
+        return condition != self.pad_value
 
     def loss(self, x, condition):
-        x = torch.where(condition == self.pad_value, 0.0, x)
-        condition = torch.where(condition == self.pad_value, 0.0, condition)
-        return torch.sum((x - condition) ** 2, dim=(1, 2, 3))
+        keep = self._known(condition)
+        zero = torch.zeros((), dtype=x.dtype, device=x.device)
+        diff = torch.where(keep, x, zero) - torch.where(keep, condition, zero)
+        return (diff * diff).sum(dim=(1, 2, 3))
 
 
 class InPainting(Painting):
-    """Condition = image with a patch set to the sentinel (likelihoods.py:75-87)."""
+    """The image with the patch blanked out (:75-87)."""
 
     def _sample(self, images):
-        h, w = self.get_random_patch(images.shape[-1])
-        condition = images.detach().clone()
-        condition[np.s_[:, :, h:h + self.patch_size, w:w + self.patch_size]] = self.pad_value
-        return condition
+        ys, xs = self._window(images)
+        out = images.detach().clone()
+        out[:, :, ys, xs] = self.pad_value
+        return out
 
 
 class OutPainting(Painting):
-    """Condition = sentinel everywhere except a patch of the image (likelihoods.py:90-104)."""
+    """Only the patch of the image is known (:90-104)."""
 
     def _sample(self, images):
-        h, w = self.get_random_patch(images.shape[-1])
-        s = np.s_[:, :, h:h + self.patch_size, w:w + self.patch_size]
-        condition = torch.ones_like(images) * self.pad_value
-        condition[s] = images[s].detach().clone()
-        return condition
+        ys, xs = self._window(images)
+        out = self.none_like(images)
+        out[:, :, ys, xs] = images[:, :, ys, xs].detach()
+        return out
 
 
 class HyperResolution(Likelihood):
-    """Bilinear down to (th, tw) then back up (likelihoods.py:107-146)."""
+    """Bilinear reduction to (target_height, target_width), then bilinear enlargement back (:107-146)."""
+
+    def __init__(self, target_height: int, target_width: int):
+        self.target_height = target_height
+        self.target_width = target_width
 
     @classmethod
     def from_configdict(cls, config):
         return cls(config["target_height"], config["target_width"])
 
-    def __init__(self, target_height: int, target_width: int):
-        self.target_height, self.target_width = target_height, target_width
-
     def _sample(self, images):
-        low = F.interpolate(images, size=(self.target_height, self.target_width), mode="bilinear", align_corners=False)
-        return F.interpolate(low, (images.shape[2], images.shape[3]), mode="bilinear")
+        small = _bilinear(images, (self.target_height, self.target_width))
+        return F.interpolate(small, tuple(images.shape[2:4]), mode="bilinear")
 
     def none_like(self, x):
         return torch.zeros_like(x)
 
     def loss(self, x, condition):
-        up = F.interpolate(condition, size=x.shape[-2:], mode="bilinear", align_corners=False)
-        return F.mse_loss(up, x)
+        return F.mse_loss(_bilinear(condition, x.shape[-2:]), x)
+
+
+_BY_NAME: Dict[str, Type[Likelihood]] = {"inpainting": InPainting, "outpainting": OutPainting, "hyperresolution": HyperResolution}
 
 
 def get_likelihood(type_: str) -> Type[Likelihood]:
-    t = type_.lower()
-    if t == "inpainting":
-        return InPainting
-    if t == "outpainting":
-        return OutPainting
-    if t == "hyperresolution":
-        return HyperResolution
-    raise NotImplementedError(f"Unknown conditioning {type_}")
+    cls = _BY_NAME.get(type_.lower())
+    if cls is None:
+        raise NotImplementedError(f"Unknown conditioning {type_}")
+    return cls

@@ -14,21 +14,24 @@ use_cuda = torch.cuda.is_available()
 device = torch.device("cuda" if use_cuda else "cpu")
 
 
-def generate_samples(model, parallel, savedir, step, net_="normal"):
-    """Save 64 generated images (8 x 8) for sanity check along training (cifar10/utils_cifar.py:13-44)."""
-    model.eval()
-    model_ = model
-    if parallel:
-        # the reference unwraps nn.DataParallel to a single device for torchdyn (utils_cifar.py:30-32)
-        model_ = model_.module.to(device)
-    node_ = NeuralODE(model_, solver="euler", sensitivity="adjoint")
+def _sample_grid(net, n_images=64, n_states=100):
+    """64 draws integrated with fixed-step Euler over linspace(0, 1, 100) (99 steps) and mapped to [0, 1]."""
+    ode = NeuralODE(net, solver="euler", sensitivity="adjoint")
+    start = torch.randn(n_images, 3, 32, 32, device=device)
+    times = torch.linspace(0, 1, n_states, device=device)
     with torch.no_grad():
-        traj = node_.trajectory(
-            torch.randn(64, 3, 32, 32, device=device),
-            t_span=torch.linspace(0, 1, 100, device=device),
-        )
-        traj = default_ops.to_unit_range(traj[-1, :].view([-1, 3, 32, 32]).contiguous())  # clip(-1, 1) / 2 + 0.5
-    save_image(traj, savedir + f"{net_}_generated_FM_images_step_{step}.png", nrow=8)
+        final = ode.trajectory(start, t_span=times)[-1]
+    return default_ops.to_unit_range(final.reshape(-1, 3, 32, 32).contiguous())   # clip(-1, 1) / 2 + 0.5, fused HIP kernel
+
+
+def generate_samples(model, parallel, savedir, step, net_="normal"):
+    """Sanity-check grid written along training (cifar10/utils_cifar.py:13-44): same signature, same file name
+    `<savedir><net_>_generated_FM_images_step_<step>.png`, 8 x 8 images; the model is put in eval mode and back in train mode."""
+    model.eval()
+    # the reference unwraps nn.DataParallel to a single device for torchdyn (utils_cifar.py:30-32)
+    net = model.module.to(device) if parallel else model
+    grid = _sample_grid(net)
+    save_image(grid, f"{savedir}{net_}_generated_FM_images_step_{step}.png", nrow=8)
     model.train()
 
 
@@ -47,7 +50,9 @@ def ema(source, target, decay):
 
 
 def infiniteloop(dataloader):
-    """cifar10/utils_cifar.py:56-59."""
-    while True:
-        for x, y in iter(dataloader):
-            yield x
+    """Endless stream of the images (labels dropped) of `dataloader` (cifar10/utils_cifar.py:56-59)."""
+    import itertools
+
+    for _epoch in itertools.count():
+        for batch in dataloader:
+            yield batch[0]

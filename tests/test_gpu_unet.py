@@ -354,3 +354,46 @@ def test_cfg4_flowers64_superres_cfm_euler_vs_oracle():
     x = x0.to(DEV).clone()
     net.engine(DEV).cfm_euler(x, ts.tolist(), cond=up.to(DEV).contiguous())
     torch.testing.assert_close(x.cpu(), ref, rtol=2e-3, atol=5e-4)
+
+
+def test_algorithmic_flops_match_survey_8d():
+    """algorithmic work per image per network evaluation, from the config alone (2 * MAC of conv / attention matmuls):
+    cfg 2 (CIFAR) 12.444 GFLOP, cfg 3 (CIFAR in=6) 12.451, cfg 4 (Flowers-64 in=6) 50.905.  The engine's plan counts them."""
+    from image_diffusion.unet import UNetModel
+
+    cases = [
+        (dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+              channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64), 12.444),
+        (dict(image_size=32, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+              channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64), 12.451),
+        (dict(image_size=64, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(4,),
+              channel_mult=(1, 2, 3, 4), num_heads=4, num_head_channels=64, use_scale_shift_norm=True, resblock_updown=True), 50.905),
+    ]
+    for kw, want in cases:
+        net = UNetModel(precision="bf16", **kw)
+        from image_diffusion.unet import param_shapes
+        net.load_state_dict(synth_state_dict(param_shapes(net), 5))
+        net.to(DEV)
+        st = net.engine(DEV).stats(1)
+        got = (st["conv_flops"] + st["attn_flops"]) / 1e9
+        assert abs(got - want) / want < 0.01, (kw["image_size"], kw["in_channels"], got, want)
+
+
+def test_utils_cifar_generate_samples_writes_grid(tmp_path):
+    """cifar10/utils_cifar.py:13-44 drop-in: 64 samples, 99 Euler steps, 8 x 8 PNG grid with the reference's file name; the model's
+    train / eval mode is restored."""
+    from PIL import Image
+
+    import utils_cifar
+    from image_diffusion.unet import param_shapes
+    from torchcfm_compat import UNetModelWrapper
+
+    net = UNetModelWrapper(dim=(3, 32, 32), num_channels=32, num_res_blocks=1, channel_mult=(1, 2), num_heads=2, attention_resolutions="16",
+                           precision="bf16")
+    net.load_state_dict(synth_state_dict(param_shapes(net), 77))
+    net.to(DEV)
+    net.train()
+    utils_cifar.generate_samples(net, False, str(tmp_path) + "/", 123, net_="ema")
+    assert net.training
+    img = Image.open(tmp_path / "ema_generated_FM_images_step_123.png")
+    assert img.size == (8 * 34 + 2, 8 * 34 + 2) and img.mode == "RGB"

@@ -243,3 +243,18 @@ def test_mnist_patch_sampler():
         assert ys.min() >= 5 and xs.min() >= 5 and ys.max() - ys.min() == 13 and xs.max() - xs.min() == 13
     with pytest.raises(NotImplementedError):
         utils_mnist.generate_samples(torch.nn.Identity(), False, "/tmp/", 0, solver="rk4")
+
+
+def test_infiniteloop_and_ema_cpu_plumbing():
+    """cifar10/utils_cifar.py:47-59: `infiniteloop` yields images only, forever; `ema` on CPU tensors is the eager expression."""
+    import utils_cifar
+
+    data = [(torch.full((2,), float(k)), torch.tensor([k])) for k in range(3)]
+    it = utils_cifar.infiniteloop(data)
+    got = [next(it)[0].item() for _ in range(7)]
+    assert got == [0.0, 1.0, 2.0, 0.0, 1.0, 2.0, 0.0]
+    src, tgt = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)
+    want = {k: v * 0.9 + src.state_dict()[k] * (1 - 0.9) for k, v in tgt.state_dict().items()}
+    utils_cifar.ema(src, tgt, 0.9)
+    for k, v in tgt.state_dict().items():
+        assert torch.equal(v, want[k])
