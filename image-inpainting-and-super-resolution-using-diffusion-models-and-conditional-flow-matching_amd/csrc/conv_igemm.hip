@@ -292,6 +292,37 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // The three taps of one kernel row with the fragment reads of tap kx + 1 issued before the MFMAs of tap kx (register double
+  // buffer): at one or two waves per SIMD nothing else hides the LDS latency between a tap's reads and its MFMAs.
+  auto mma_row3 = [&](const char* pa_, const int (&ao)[MI], const char* wt, const int (&bo)[NI]) {
+#ifdef CONV_STAMPS
+    if (p.ablate & (32 | 4)) { mma_tap(pa_, ao, 0, wt, bo); mma_tap(pa_, ao, PROW, wt + WTILE, bo); mma_tap(pa_, ao, 2 * PROW, wt + 2 * WTILE, bo); return; }
+#endif
+    u32x4 a[2][MI], b[2][NI];
+    auto rd = [&](auto bufc, auto kxc) {
+      constexpr int buf = decltype(bufc)::value, kx = decltype(kxc)::value;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[buf][mi] = *reinterpret_cast<const u32x4*>(pa_ + ao[mi] + kx * PROW);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[buf][ni] = *reinterpret_cast<const u32x4*>(wt + kx * WTILE + bo[ni]);
+    };
+    auto mm = [&](auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], b[buf][ni], a[buf][mi], T());
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    rd(IC<0>(), IC<0>());
+    rd(IC<1>(), IC<1>());
+    mm(IC<0>());
+    rd(IC<0>(), IC<2>());
+    mm(IC<1>());
+    mm(IC<0>());
+  };
+
   int gi = 0;  // kernel-row counter (weight buffer parity)
   // Two workgroups share a CU and would otherwise run their staging / MFMA / store phases in lockstep (measured: the
   // phase costs simply add up).  Delaying the workgroup in the odd threadgroup slot of the CU (HW_ID.TG_ID, bits 19:16)
@@ -326,12 +357,9 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
         if (nxt < p.nchunks * 9) prefetch_w(nxt, IC<slot>());
         STAMP(5)
         const char* wt = wlds + (gi & 1) * (3 * WTILE);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          if (ky == 0) mma_tap(patch, arow, kx * PROW, wt + kx * WTILE, brow);
-          else if (ky == 1) mma_tap(patch, a1, kx * PROW, wt + kx * WTILE, brow);
-          else mma_tap(patch, a2, kx * PROW, wt + kx * WTILE, brow);
-        }
+        if (ky == 0) mma_row3(patch, arow, wt, brow);
+        else if (ky == 1) mma_row3(patch, a1, wt, brow);
+        else mma_row3(patch, a2, wt, brow);
         STAMP(6)
         ++gi;
       };
