@@ -32,16 +32,18 @@ __device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, uint32_t voff
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <typename T, int BM>
+// GC: channel chunks per weight group (one barrier per group).  GC = 1 shrinks the weight double buffer to 16 KB so that a 128-pixel
+// tile of 256 input channels still fits twice per CU: half the weight bytes streamed from L2 per FLOP of the 64-pixel tile.
+template <typename T, int BM, int GC>
 __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK, ESZ = sizeof(T);
   constexpr bool FAST = (E::DTYPE == 1);
   constexpr int BN = 128, WN = 2, WTM = BM / 2, WTN = 64, MI = WTM / 16, NI = 4;
-  constexpr int WTILE = BN * 64, WIT = 3 * WTILE / (NT1 * 16), PIT = BM / 64, APL = BM * 64;
+  constexpr int WTILE = BN * 64, WIT = GC * WTILE / (NT1 * 16), PIT = BM / 64, APL = BM * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* alds = smem;                          // [nchunks][BM][64 B], 16-B slots XOR-swizzled by (row >> 1) & 3
-  char* wlds = smem + p.nchunks * APL;        // two buffers of 3 weight tiles
+  char* wlds = smem + p.nchunks * APL;        // two buffers of GC weight tiles
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -125,13 +127,13 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
 #pragma unroll
   for (int i = 0; i < WIT; ++i) woff[i] = (i * NT1 + tid) * 16;   // three consecutive 8 KB tiles
   u32x4 wreg[WIT];
-  const int ngroups = (p.nchunks + 2) / 3;
+  const int ngroups = (p.nchunks + GC - 1) / GC;
   const int nt0 = blockIdx.y * p.ntn;
   const int ntn = min(p.ntn, p.Cout / BN - nt0);
   const int total = ntn * ngroups;
   auto prefetch_w = [&](int gidx) {
     const int nti = gidx / ngroups, g = gidx - nti * ngroups;
-    const uint32_t so = ((uint32_t)(nt0 + nti) * p.nchunks + 3 * g) * WTILE;
+    const uint32_t so = ((uint32_t)(nt0 + nti) * p.nchunks + GC * g) * WTILE;
 #pragma unroll
     for (int i = 0; i < WIT; ++i) wreg[i] = bload16(rsw, woff[i], so);   // past-the-end tiles of a short last group read as 0
   };
@@ -175,15 +177,15 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
           for (int k = 0; k < NP2; ++k)
             rr[mi][k] = bload16(rsr, ovalid[mi] ? (opix[mi] * (uint32_t)p.Cout + co_s + k * PSTEP) * ESZ : p.obytes, 0);
       }
-      char* wb = wlds + (gi & 1) * (3 * WTILE);
+      char* wb = wlds + (gi & 1) * (GC * WTILE);
 #pragma unroll
       for (int i = 0; i < WIT; ++i) *reinterpret_cast<u32x4*>(wb + (i * NT1 + tid) * 16) = wreg[i];
       __syncthreads();   // weights of this group (and, the first time, the activation tile) visible; orders buffer reuse
       if (gi + 1 < total) prefetch_w(gi + 1);
-      const int nc = min(3, p.nchunks - 3 * g);
-      const char* ab = alds + 3 * g * APL;
+      const int nc = min(GC, p.nchunks - GC * g);
+      const char* ab = alds + GC * g * APL;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < GC; ++j) {
         if (j < nc) {
           u32x4 a[MI], b[NI];
 #pragma unroll
@@ -249,9 +251,9 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
   }
 }
 
-template <typename T, int BM>
+template <typename T, int BM, int GC>
 void launch1(const K1Args& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv1x1_kernel<T, BM>;
+  auto kern = conv1x1_kernel<T, BM, GC>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -270,13 +272,16 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream) {
   const int CH = d.dtype == 0 ? 16 : 32, esz = d.dtype == 0 ? 4 : 2;
   const int Cin = d.C0 + d.C1, nchunks = Cin / CH;
   if (d.C0 % CH || d.C1 % CH) return 1;
-  const size_t wl = 2 * 3 * 128 * 64;
-  int BM = 0;
-  if ((size_t)nchunks * 128 * 64 + wl <= 80 * 1024) BM = 128;
-  else if ((size_t)nchunks * 64 * 64 + wl <= 160 * 1024) BM = 64;
-  else return 1;
   const long M = (long)d.N * d.Hs * d.Ws;
-  if (BM == 128 && (M + 127) / 128 < 512) BM = 64;
+  // tile choice: 128 pixels while two workgroups fit a CU (80 KB each) - with the one-chunk weight groups if the three-chunk
+  // double buffer would not fit - else 64 pixels
+  int BM = 64, GC = 3;
+  if ((M + 127) / 128 >= 512) {
+    if ((size_t)nchunks * 128 * 64 + 2 * 3 * 8192 <= 80 * 1024) { BM = 128; GC = 3; }
+    else if ((size_t)nchunks * 128 * 64 + 2 * 1 * 8192 <= 80 * 1024) { BM = 128; GC = 1; }
+  }
+  const size_t wl = 2 * (size_t)GC * 8192;
+  if ((size_t)nchunks * BM * 64 + wl > 160 * 1024) return 1;
   // A stationary tile only pays when it is reused by several output-channel tiles or when two workgroups still fit a CU
   if ((size_t)nchunks * BM * 64 + wl > 80 * 1024 && d.Cout / 128 < 3) return 1;
   K1Args a;
@@ -311,8 +316,15 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream) {
   a.obytes = (uint32_t)ob;
   dim3 grid(mt, (ntiles + ntn - 1) / ntn);
   const size_t lds = (size_t)nchunks * BM * 64 + wl;
-  if (d.dtype == 0) { if (BM == 128) launch1<float, 128>(a, grid, lds, stream); else launch1<float, 64>(a, grid, lds, stream); }
-  else { if (BM == 128) launch1<bf16, 128>(a, grid, lds, stream); else launch1<bf16, 64>(a, grid, lds, stream); }
+  if (d.dtype == 0) {
+    if (BM == 128 && GC == 3) launch1<float, 128, 3>(a, grid, lds, stream);
+    else if (BM == 128) launch1<float, 128, 1>(a, grid, lds, stream);
+    else launch1<float, 64, 3>(a, grid, lds, stream);
+  } else {
+    if (BM == 128 && GC == 3) launch1<bf16, 128, 3>(a, grid, lds, stream);
+    else if (BM == 128) launch1<bf16, 128, 1>(a, grid, lds, stream);
+    else launch1<bf16, 64, 3>(a, grid, lds, stream);
+  }
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }
