@@ -206,9 +206,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     // Together with the wave's own LDS writes (lgkmcnt 0) this is all the coming barrier has to order, so the loaders use the bare
     // s_barrier: __syncthreads()'s workgroup release fence would drain vmcnt to 0 (the DMA counts as an LDS write), i.e. wait for
     // the next row's DMA and the next chunk's patch fragments at every kernel row.
-    auto publish_row = [&]() {
+    auto wait_landed = [&]() {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(8 | (7 << 4) | (0 << 8));   // vmcnt(8) lgkmcnt(0)
+    };
+    auto bare_barrier = [&]() {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     };
@@ -266,7 +268,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         auto tail = [&]() {
           dma_w();
           STAMP(3)
-          publish_row();               // kernel row (t, c, ky) and its patch are in LDS
+          wait_landed();
+          STAMP(1)                     // (diagnostic build: slot 1 = time spent in the counted wait)
+          bare_barrier();              // kernel row (t, c, ky) and its patch are in LDS
           STAMP(4)
         };
         // ---- ky = 0 ----
