@@ -33,16 +33,27 @@ def load_checkpoint(net, path):
     return net
 
 
-def make_gen_1_img(new_net, batch_size_fid=1024, integration_steps=100, integration_method="euler", device="cuda:0", tol=1e-5):
+def draw_x0_shard(batch, seed, call_idx, device, shape=(3, 32, 32)):
+    """This rank's slice of the batch's initial noise.  Every rank draws the SAME [batch, *shape] tensor from a generator seeded
+    with seed + call_idx and keeps rows shard_range(batch), so an N-rank run integrates exactly the x0 of the 1-rank run
+    (the reference's single `torch.randn(batch_size_fid, 3, 32, 32)`, cifar10/compute_fid.py:75, re-sharded)."""
+    lo, hi = mdist.shard_range(batch)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) + int(call_idx))
+    return torch.randn(batch, *shape, device=device, generator=g)[lo:hi].contiguous()
+
+
+def make_gen_1_img(new_net, batch_size_fid=1024, integration_steps=100, integration_method="euler", device="cuda:0", tol=1e-5, seed=0):
     if integration_method not in ("euler", "dopri5"):
         raise NotImplementedError("--integration_method must be euler or dopri5")
     device = torch.device(device)
+    calls = [0]
 
     def gen_1_img(unused_latent):
         with torch.no_grad():
             B = int(batch_size_fid)
-            lo, hi = mdist.shard_range(B)
-            x = torch.randn(B, 3, 32, 32, device=device)[lo:hi].contiguous()  # same draw on every rank, rank takes its slice
+            x = draw_x0_shard(B, seed, calls[0], device)
+            calls[0] += 1
             if integration_method == "euler":
                 t_span = torch.linspace(0, 1, integration_steps + 1).tolist()
                 _, _, img = new_net.engine(device).cfm_euler(x, t_span, want_u8=True)  # (traj*127.5+128).clip(0,255).to(uint8)
@@ -68,6 +79,7 @@ def main(argv=None):
     ap.add_argument("--step", type=int, default=400000)
     ap.add_argument("--num_gen", type=int, default=50000)
     ap.add_argument("--batch_size_fid", type=int, default=1024)
+    ap.add_argument("--seed", type=int, default=0, help="x0 stream seed, shared by all ranks (each takes its batch slice)")
     a = ap.parse_args(argv)
     rank, world, local = mdist.init_from_env()
     device = f"cuda:{local}"
@@ -75,7 +87,7 @@ def main(argv=None):
     path = f"{a.input_dir}/{a.model}/{a.model}_cifar10_weights_step_{a.step}.pt"
     print("path: ", path)
     load_checkpoint(net, path)
-    gen = make_gen_1_img(net, a.batch_size_fid, a.integration_steps, a.integration_method, device, a.tol)
+    gen = make_gen_1_img(net, a.batch_size_fid, a.integration_steps, a.integration_method, device, a.tol, a.seed)
     try:
         from cleanfid import fid
     except ImportError as e:

@@ -80,9 +80,8 @@ int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const fl
   MI355_REQUIRE(net && recs && cap > 0, -1, "unet_profile: bad argument");
   std::vector<mi355_op_profile> prof;
   std::vector<hipEvent_t> ev;
-  net->prof = &prof; net->prof_events = &ev;
-  int rc = unet_forward(net, x, x_channels, cond, cond_channels, t, out, batch, workspace, workspace_bytes, S(stream));
-  net->prof = nullptr; net->prof_events = nullptr;
+  UnetRun run; run.prof = &prof; run.prof_events = &ev;
+  int rc = unet_forward(net, x, x_channels, cond, cond_channels, t, out, batch, workspace, workspace_bytes, S(stream), run);
   // An event record is itself a packet the queue has to retire: an interval between two events holds one such gap besides the
   // op.  Calibrate it on this stream (back-to-back records with nothing in between) and take it off every interval, so the
   // per-op times agree with rocprofv3's kernel durations.
@@ -113,7 +112,7 @@ int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const fl
 
 struct Scratch { float* t; float* v; float* none; char* unet_ws; int64_t unet_bytes; };
 // every image of a sampler step shares the step time: the engine computes ONE embedding row (stride-0 broadcast)
-struct UniformT { mi355_unet* n; explicit UniformT(mi355_unet* n_) : n(n_) { n->t_uniform = 1; } ~UniformT() { n->t_uniform = 0; } };
+static UnetRun uniform_t_run() { UnetRun r; r.t_uniform = 1; return r; }
 static int carve(mi355_unet* net, int B, void* workspace, int64_t workspace_bytes, Scratch& sc) {
   MI355_REQUIRE(net && workspace, -1, "null argument");
   MI355_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, -1, "workspace must be 256-byte aligned");
@@ -128,23 +127,35 @@ static int carve(mi355_unet* net, int B, void* workspace, int64_t workspace_byte
   return 0;
 }
 
-int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const float* cond, int cond_channels,
+int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const float* cond, int cond_channels, int cond_drift,
                            const float* t_span_host, int n_t, float* traj, uint8_t* u8_out, int batch, void* workspace,
                            int64_t workspace_bytes, void* stream) {
   MI355_REQUIRE(net && x && t_span_host && n_t >= 1, -1, "cfm_euler_sample: bad argument");
   MI355_REQUIRE(x_channels == net->cfg.out_channels, -2, "cfm_euler_sample: the vector field must have the state's channel count");
   Scratch sc;
   if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
-  UniformT uniform_guard(net);
+  const UnetRun run = uniform_t_run();
   hipStream_t s = S(stream);
   const int64_t n = (int64_t)batch * x_channels * net->cfg.image_size * net->cfg.image_size;
+  const int64_t nc = (int64_t)batch * cond_channels * net->cfg.image_size * net->cfg.image_size;
   if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  // cond_drift: the reference integrates the CONCATENATED state [x, con] whose second half has derivative con itself
+  // (mnist/utils_mnist2.py:120-124), so under Euler the condition the model sees is con_{k+1} = con_k + dt * con_k.
+  // The drifting copy lives in the sampler scratch (the caller's tensor is not modified).
+  float* cdrift = nullptr;
+  if (cond && cond_drift) {
+    MI355_REQUIRE(cond_channels <= 32, -2, "cfm_euler_sample: condition has more than 32 channels");
+    cdrift = sc.none;
+    MI355_CHECK_HIP(hipMemcpyAsync(cdrift, cond, (size_t)nc * 4, hipMemcpyDeviceToDevice, s));
+    cond = cdrift;
+  }
   for (int k = 0; k + 1 < n_t; ++k) {
     const float t = t_span_host[k], dt = t_span_host[k + 1] - t_span_host[k];
     int rc;
     if ((rc = fill_launch(sc.t, t, batch, s))) return rc;
-    if ((rc = unet_forward(net, x, x_channels, cond, cond_channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s))) return rc;
+    if ((rc = unet_forward(net, x, x_channels, cond, cond_channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s, run))) return rc;
     if ((rc = euler_step_launch(x, sc.v, dt, n, s))) return rc;
+    if (cdrift && (rc = euler_step_launch(cdrift, cdrift, dt, nc, s))) return rc;
     if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * n, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
   }
   if (u8_out) return quantize_u8_launch(x, u8_out, n, s);
@@ -163,7 +174,7 @@ int mi355_ddpm_sample(mi355_unet* net, float* x, int channels, const float* cond
   MI355_REQUIRE(mode != MI355_DDPM_AMORTIZED || (amortized && cond), -2, "ddpm_sample: amortized needs a 2C-input net and a condition");
   Scratch sc;
   if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
-  UniformT uniform_guard(net);
+  const UnetRun run = uniform_t_run();
   hipStream_t s = S(stream);
   const int64_t n = (int64_t)batch * channels * net->cfg.image_size * net->cfg.image_size;
   const int64_t n_al = (n + 3) / 4 * 4;
@@ -191,7 +202,7 @@ int mi355_ddpm_sample(mi355_unet* net, float* x, int channels, const float* cond
                                     tb->sqrt_one_minus_alphas_cumprod[i], ph, opt->seed, off, n, s))) return rc;
     }
     if ((rc = fill_launch(sc.t, tval, batch, s))) return rc;
-    if ((rc = unet_forward(net, x, channels, cond_pred, channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s))) return rc;
+    if ((rc = unet_forward(net, x, channels, cond_pred, channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s, run))) return rc;
     if (mode == MI355_DDIM) {
       if ((rc = ddim_step_launch(x, sc.v, tb->sqrt_recip_alphas_cumprod[i], tb->sqrt_recipm1_alphas_cumprod[i],
                                  tb->alphas_cumprod_prev[i], n, s))) return rc;
@@ -203,7 +214,7 @@ int mi355_ddpm_sample(mi355_unet* net, float* x, int channels, const float* cond
     if ((rc = ddpm_step_launch(x, sc.v, z, tb->sqrt_recip_alphas_cumprod[i], tb->sqrt_recipm1_alphas_cumprod[i],
                                tb->posterior_mean_coef1[i], tb->posterior_mean_coef2[i], sigma, ph, opt->seed, off, n, s))) return rc;
     for (int c = 0; c < opt->n_corrector; ++c) {
-      if ((rc = unet_forward(net, x, channels, cond_corr, channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s))) return rc;
+      if ((rc = unet_forward(net, x, channels, cond_corr, channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s, run))) return rc;
       const float* z2 = nullptr; int ph2 = 0; uint64_t off2 = 0;
       if ((rc = next_noise(z2, ph2, off2))) return rc;
       const float dt = (opt->tmax - opt->tmin) / (float)Ns;
@@ -250,6 +261,10 @@ int mi355_mse_per_sample(const float* a, const float* b, float* out, int batch, 
   MI355_REQUIRE(a && b && out, -1, "mse_per_sample: null argument");
   return mse_per_sample_launch(a, b, out, batch, elems_per_sample, S(stream));
 }
+int mi355_lincomb_per_sample(float* out, const float* x, const float* y, const float* a, const float* b, int batch,
+                             int64_t elems_per_sample, void* stream) {
+  return lincomb_per_sample_launch(out, x, y, a, b, batch, elems_per_sample, S(stream));
+}
 int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream) { return quantize_u8_launch(x, out, n, S(stream)); }
 int mi355_to_unit_range(const float* x, float* out, int64_t n, void* stream) { return to_unit_range_launch(x, out, n, S(stream)); }
 int mi355_randn(float* out, uint64_t seed, uint64_t offset, int64_t n, void* stream) { return randn_launch(out, seed, offset, n, S(stream)); }
@@ -275,52 +290,66 @@ int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw) {
   return (int64_t)(2 * al256((size_t)batch * hw * 4 * c * 4) + al256(c * c * 9 * 4 * 2) + 4 * al256((size_t)batch * c * 4) + (1 << 20));
 }
 
-int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, float* y, int batch, int cin, int h, int w, int cout,
-                 int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu, int dtype,
-                 void* workspace, int64_t workspace_bytes, void* stream) {
+int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
+                 int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
+                 const float* emb, const float* res, int res_mode, int dtype, void* workspace, int64_t workspace_bytes,
+                 void* stream) {
   MI355_REQUIRE(x && w_host && y && workspace, -1, "conv2d: null argument");
   MI355_REQUIRE(dtype == 0 || dtype == 1, -1, "conv2d: bad dtype");
   MI355_REQUIRE(stride == 1 || stride == 2, -1, "conv2d: stride must be 1 or 2");
   MI355_REQUIRE(!(stride == 2 && resample), -1, "conv2d: stride 2 cannot be combined with resampling");
+  MI355_REQUIRE((x1 != nullptr) == (cin1 > 0), -1, "conv2d: x1 and cin1 go together");
+  MI355_REQUIRE(res == nullptr || res_mode == RES_SAME || res_mode == RES_UP2, -1, "conv2d: res_mode must be 1 (same size) or 2 (nearest x2)");
   hipStream_t s = S(stream);
   const int CH = dtype == 0 ? 16 : 32, esz = dtype == 0 ? 4 : 2;
+  MI355_REQUIRE(!x1 || (cin % CH == 0 && cin1 % CH == 0), -2, "conv2d: a two-source conv needs both channel counts to be multiples of the 64-byte chunk");
   const int cpad = (cin + CH - 1) / CH * CH;
-  ConvDesc d; d.dtype = dtype; d.N = batch; d.Hs = h; d.Ws = w; d.C0 = cpad; d.ks = ksize; d.Cout = cout;
+  const int ctot = cin + cin1, ctot_pad = cpad + cin1;
+  ConvDesc d; d.dtype = dtype; d.N = batch; d.Hs = h; d.Ws = w; d.C0 = cpad; d.C1 = cin1; d.ks = ksize; d.Cout = cout;
   const bool pool = resample == 3;   // 2x2 average pool of the (normalised) input: a pre-pass, then a plain conv
+  MI355_REQUIRE(!(pool && x1), -4, "conv2d: pooling over a channel concat is not supported");
   if (pool) { d.Hs = h / 2; d.Ws = w / 2; }
   d.mode = stride == 2 ? CONV_STRIDE2 : (resample == 2 ? CONV_UP2 : CONV_UNIT);
   const ConvGeom g = conv_geometry(d);
+  const bool nhwc = cout % 4 == 0;
+  MI355_REQUIRE(nhwc || (!emb && !res), -4, "conv2d: emb / residual epilogues need an NHWC output (cout % 4 == 0)");
+  const int Hr = res_mode == RES_UP2 ? g.Ho / 2 : g.Ho, Wr = res_mode == RES_UP2 ? g.Wo / 2 : g.Wo;
   char* p = reinterpret_cast<char*>(workspace);
   char* end = p + workspace_bytes;
   void* xin = p; p += al256((size_t)batch * h * w * cpad * esz);
-  void* wdev = p; const size_t wbytes = conv_packed_weight_bytes(dtype, cout, cin, ksize); p += al256(wbytes);
+  void* xin1 = p; if (x1) p += al256((size_t)batch * h * w * cin1 * esz);
+  void* wdev = p; const size_t wbytes = conv_packed_weight_bytes(dtype, cout, ctot, ksize); p += al256(wbytes);
   float* bdev = reinterpret_cast<float*>(p); p += al256((size_t)cout * 4);
-  float* ga = reinterpret_cast<float*>(p); p += al256((size_t)batch * cpad * 4);
-  float* gb = reinterpret_cast<float*>(p); p += al256((size_t)batch * cpad * 4);
-  float* gpad = reinterpret_cast<float*>(p); p += 2 * al256((size_t)cpad * 4);
+  float* ga = reinterpret_cast<float*>(p); p += al256((size_t)batch * ctot_pad * 4);
+  float* gb = reinterpret_cast<float*>(p); p += al256((size_t)batch * ctot_pad * 4);
   void* yout = p; p += al256((size_t)batch * g.Ho * g.Wo * cout * esz);
+  void* rin = p; if (res) p += al256((size_t)batch * Hr * Wr * cout * esz);
   void* xpool = p; if (pool) p += al256((size_t)batch * (h / 2) * (w / 2) * cpad * esz);
   MI355_REQUIRE(p <= end, -2, "conv2d: workspace too small");
   int rc;
   if ((rc = pack_nhwc_launch(dtype, x, cin, nullptr, 0, batch, h * w, cpad, xin, s))) return rc;
+  if (x1 && (rc = pack_nhwc_launch(dtype, x1, cin1, nullptr, 0, batch, h * w, cin1, xin1, s))) return rc;
+  if (res && (rc = pack_nhwc_launch(dtype, res, cout, nullptr, 0, batch, Hr * Wr, cout, rin, s))) return rc;
   std::vector<char> packed(wbytes);
-  conv_pack_weights(dtype, w_host, cout, cin, ksize, packed.data());
+  conv_pack_weights(dtype, w_host, cout, ctot, ksize, packed.data());
   MI355_CHECK_HIP(hipMemcpyAsync(wdev, packed.data(), wbytes, hipMemcpyHostToDevice, s));
   if (bias_host) MI355_CHECK_HIP(hipMemcpyAsync(bdev, bias_host, (size_t)cout * 4, hipMemcpyHostToDevice, s));
   if (gn_gamma) {
-    MI355_REQUIRE(cin % 32 == 0, -2, "conv2d: the GroupNorm32 prologue needs cin % 32 == 0");
-    GnDesc gd; gd.dtype = dtype; gd.src0 = xin; gd.C0 = cpad; gd.N = batch; gd.HW = h * w; gd.gamma = gn_gamma; gd.beta = gn_beta;
+    MI355_REQUIRE(ctot % 32 == 0 && cin % 32 == 0, -2, "conv2d: the GroupNorm32 prologue needs channels % 32 == 0");
+    GnDesc gd; gd.dtype = dtype; gd.src0 = xin; gd.C0 = cpad; gd.src1 = x1 ? xin1 : nullptr; gd.C1 = cin1; gd.N = batch; gd.HW = h * w;
+    gd.gamma = gn_gamma; gd.beta = gn_beta;
     gd.a = ga; gd.b = gb;
-    (void)gpad;
     if ((rc = gn_affine_launch(gd, s))) return rc;
     if (!pool) { d.pro_a = ga; d.pro_b = gb; d.pro_silu = gn_silu; }
   }
+  if (x1) d.src1 = xin1;
+  if (emb) { d.emb = emb; d.emb_stride = cout; }
+  if (res) { d.res = rin; d.res_mode = res_mode; }
   d.src0 = xin;
   if (pool) {
     if ((rc = affine_pool_launch(dtype, xin, gn_gamma ? ga : nullptr, gn_gamma ? gb : nullptr, gn_silu, xpool, batch, h, w, cpad, s))) return rc;
     d.src0 = xpool;
   } d.w = wdev; d.bias = bias_host ? bdev : nullptr;
-  const bool nhwc = cout % 4 == 0;
   d.out_mode = nhwc ? OUT_NHWC : OUT_NCHW_F32;
   d.out = nhwc ? yout : (void*)y;
 #ifdef CONV_STAMPS
@@ -340,7 +369,7 @@ int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, fl
     MI355_CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     MI355_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    const double us = 1e3 * ms / reps, fl = 2.0 * batch * g.Ho * g.Wo * (double)cout * cin * ksize * ksize;
+    const double us = 1e3 * ms / reps, fl = 2.0 * batch * g.Ho * g.Wo * (double)cout * ctot * ksize * ksize;
     fprintf(stderr, "[conv time] %d launches, %.1f us each, %.0f TFLOP/s\n", reps, us, fl / us * 1e-6);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <cstring>
 #include <string>
 
@@ -97,3 +98,23 @@ void mi355_set_error(const std::string& msg);
       return code;                                                                                  \
     }                                                                                               \
   } while (0)
+
+// Allow a kernel more than 64 KB of dynamic LDS (the CU has 160 KB).  The attribute is per (function, device): one bit per device
+// per kernel instantiation (the static lives in this template's instantiation), set once, thread-safe, and a failure is reported
+// instead of surfacing later as an opaque launch error.
+template <typename K>
+int mi355_allow_big_lds(K kern, const char* what) {
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  MI355_CHECK_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    mi355_set_error(std::string(what) + ": hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KB) failed: " + hipGetErrorString(e));
+    return -3;
+  }
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}

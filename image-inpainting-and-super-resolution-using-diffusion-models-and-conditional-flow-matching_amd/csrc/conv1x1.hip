@@ -252,15 +252,11 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
 }
 
 template <typename T, int BM, int GC>
-void launch1(const K1Args& a, dim3 grid, size_t lds, hipStream_t s) {
+int launch1(const K1Args& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv1x1_kernel<T, BM, GC>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) (void)hipGetLastError();
-    attr_done = true;
-  }
+  if (int rc = mi355_allow_big_lds(kern, "conv1x1")) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(NT1), lds, s, a);
+  return 0;
 }
 
 }  // namespace
@@ -316,15 +312,17 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream) {
   a.obytes = (uint32_t)ob;
   dim3 grid(mt, (ntiles + ntn - 1) / ntn);
   const size_t lds = (size_t)nchunks * BM * 64 + wl;
+  int rc;
   if (d.dtype == 0) {
-    if (BM == 128 && GC == 3) launch1<float, 128, 3>(a, grid, lds, stream);
-    else if (BM == 128) launch1<float, 128, 1>(a, grid, lds, stream);
-    else launch1<float, 64, 3>(a, grid, lds, stream);
+    if (BM == 128 && GC == 3) rc = launch1<float, 128, 3>(a, grid, lds, stream);
+    else if (BM == 128) rc = launch1<float, 128, 1>(a, grid, lds, stream);
+    else rc = launch1<float, 64, 3>(a, grid, lds, stream);
   } else {
-    if (BM == 128 && GC == 3) launch1<bf16, 128, 3>(a, grid, lds, stream);
-    else if (BM == 128) launch1<bf16, 128, 1>(a, grid, lds, stream);
-    else launch1<bf16, 64, 3>(a, grid, lds, stream);
+    if (BM == 128 && GC == 3) rc = launch1<bf16, 128, 3>(a, grid, lds, stream);
+    else if (BM == 128) rc = launch1<bf16, 128, 1>(a, grid, lds, stream);
+    else rc = launch1<bf16, 64, 3>(a, grid, lds, stream);
   }
+  if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }

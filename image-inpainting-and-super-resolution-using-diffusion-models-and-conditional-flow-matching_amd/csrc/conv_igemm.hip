@@ -514,12 +514,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
 template <typename T, int BM, int BN, int WM, int WN, int KS, int PIT, bool MULTI>
 int launch_m(const ConvKArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, KS, PIT, MULTI>;
-  static bool attr_done = false;  // allow > 64 KB of dynamic LDS (the CU has 160 KB)
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { (void)hipGetLastError(); }
-    attr_done = true;
-  }
+  if (int rc = mi355_allow_big_lds(kern, "conv")) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
   return 0;
 }
@@ -717,6 +712,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
     const int r = d.dtype == 0 ? launch_ws<float>(a, g.BM, g.BN, d.ks, stream) : launch_ws<bf16>(a, g.BM, g.BN, d.ks, stream);
     if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
+    if (r < 0) return r;
   }
   int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream)
                         : launch_cfg<bf16>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream);

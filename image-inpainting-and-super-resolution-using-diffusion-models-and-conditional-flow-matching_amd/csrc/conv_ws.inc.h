@@ -525,7 +525,7 @@ static bool ws_eligible(int ks, int BM, int BN, int G, int bn_pack, int out_mode
   return n_mt * n_nt >= ws_num_cus();   // fewer tiles than CUs: the plain kernel's smaller tiles fill the chip better
 }
 
-// 0 = launched, 1 = not eligible (caller uses the plain kernel)
+// 0 = launched, 1 = not eligible (caller uses the plain kernel), < 0 = error
 template <typename T>
 int launch_ws(ConvKArgs a, int BM, int BN, int ks, hipStream_t s) {
   if (!ws_eligible(ks, BM, BN, a.G, a.bn_pack, a.out_mode, a.stride, a.nchunks, a.N, a.Ho, a.Wo, a.Cout)) return 1;
@@ -533,15 +533,12 @@ int launch_ws(ConvKArgs a, int BM, int BN, int ks, hipStream_t s) {
   a.tiles_x = (a.Wo + ws::VW - 1) / ws::VW; a.tiles_y = (a.Ho + ws::TH - 1) / ws::TH;
   const int n_mt = a.N * a.tiles_x * a.tiles_y, n_nt = (a.Cout + 127) / 128;
   const int ncu = ws_num_cus();
+  int rc;
+  if (!a.pro_a) rc = mi355_allow_big_lds(conv3x3_ws_kernel<T, 0>, "conv3x3 (persistent)");
+  else if (a.pro_silu) rc = mi355_allow_big_lds(conv3x3_ws_kernel<T, 2>, "conv3x3 (persistent)");
+  else rc = mi355_allow_big_lds(conv3x3_ws_kernel<T, 1>, "conv3x3 (persistent)");
+  if (rc) return rc;
   auto kern = !a.pro_a ? conv3x3_ws_kernel<T, 0> : (a.pro_silu ? conv3x3_ws_kernel<T, 2> : conv3x3_ws_kernel<T, 1>);
-  static bool attr_done = false;
-  if (!attr_done) {
-    for (auto k : {conv3x3_ws_kernel<T, 0>, conv3x3_ws_kernel<T, 1>, conv3x3_ws_kernel<T, 2>}) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) (void)hipGetLastError();
-    }
-    attr_done = true;
-  }
   const int ntp = ((n_mt + 7) / 8) * 8 * n_nt;
   const int grid = ntp < ncu ? ntp : ncu;   // one persistent workgroup per CU
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ws::LDS_BYTES, s, a, n_mt, n_nt);

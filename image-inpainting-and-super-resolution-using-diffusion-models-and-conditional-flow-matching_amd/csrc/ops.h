@@ -106,6 +106,8 @@ int replace_mask_launch(float* x, const float* cond, const float* z, float pad, 
                         int use_philox, uint64_t seed, uint64_t offset, int64_t n, hipStream_t s);
 int clip_launch(float* x, float lo, float hi, int64_t n, hipStream_t s);
 int mse_per_sample_launch(const float* a, const float* b, float* out, int batch, int64_t per, hipStream_t s);
+int lincomb_per_sample_launch(float* out, const float* x, const float* y, const float* a, const float* b, int batch, int64_t per,
+                              hipStream_t s);
 int ema_update_launch(float* target, const float* source, float decay, float one_minus_decay, int64_t n, hipStream_t s);
 int quantize_u8_launch(const float* x, uint8_t* out, int64_t n, hipStream_t s);
 int to_unit_range_launch(const float* x, float* out, int64_t n, hipStream_t s);

@@ -248,3 +248,26 @@ int fill_launch(float* x, float v, int64_t n, hipStream_t s) {
     st4(x, i, cnt, a);
   });
 }
+
+// out[n, :] = a[n] * x[n, :] + b[n] * y[n, :] with per-sample coefficients (device arrays gathered from the DDPM tables by
+// `extract`, sde_diffusion.py:101-104): predict_start_from_noise / q_posterior mean / q_sample / score_from_x0
+// (sde_diffusion.py:214-244).  Two separately rounded products and one add, like the reference's eager expression; y (and b)
+// may be null (out = a * x).  `per` = elements per sample.
+int lincomb_per_sample_launch(float* out, const float* x, const float* y, const float* a, const float* b, int batch, int64_t per,
+                              hipStream_t s) {
+  MI355_REQUIRE(out && x && a && batch > 0 && per > 0, -1, "lincomb_per_sample: bad argument");
+  MI355_REQUIRE((y == nullptr) == (b == nullptr), -1, "lincomb_per_sample: y and b go together");
+  const int64_t n = (int64_t)batch * per;
+  return launch_ew4(n, s, [=] __device__(int64_t i, int64_t, int cnt) {
+    float xv[4], yv[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+    ld4(x, i, cnt, xv);
+    if (y) ld4(y, i, cnt, yv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t smp = (i + j) / per;   // a 4-element group may straddle two samples when per % 4 != 0
+      const int64_t sc = smp < batch ? smp : batch - 1;
+      o[j] = y ? a[sc] * xv[j] + b[sc] * yv[j] : a[sc] * xv[j];
+    }
+    st4(out, i, cnt, o);
+  });
+}

@@ -48,8 +48,13 @@ struct mi355_unet {
   int in_tensor = -1, out_channels = 0;
   // stats per image
   double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;
-  int64_t launches = 0;
-  int t_uniform = 0;   // set by the sampler loops: t[0] holds for the whole batch
+  int64_t launches = 0;   // device launches of one forward (fixed by the plan)
+};
+
+// Per-call options of unet_forward.  They are arguments, not handle state: a handle is immutable after unet_build, so one
+// handle may be driven from several host threads / streams (each with its own workspace).
+struct UnetRun {
+  int t_uniform = 0;   // sampler loops: t[0] holds for the whole batch (one embedding row, stride-0 broadcast)
   // optional per-op profiling (mi355_unet_profile)
   std::vector<mi355_op_profile>* prof = nullptr;
   std::vector<hipEvent_t>* prof_events = nullptr;
@@ -59,5 +64,5 @@ int unet_build(const mi355_unet_config& cfg, const float* const* params_host, in
                int64_t dev_weights_bytes, hipStream_t stream, mi355_unet** out);
 int64_t unet_weight_bytes(const mi355_unet_config& cfg);
 int64_t unet_workspace_bytes(const mi355_unet* net, int batch);
-int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int batch,
-                 void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int batch,
+                 void* workspace, int64_t workspace_bytes, hipStream_t stream, const UnetRun& run = UnetRun());

@@ -263,6 +263,7 @@ struct Walker {
     }
     net->conv_flops += 2.0 * (double)K * emb_total + 2.0 * (double)mc * K + 2.0 * (double)K * K;
     net->out_channels = cfg.out_channels;
+    net->launches = 5 + (int64_t)net->ops.size();
     return 0;
   }
 };
@@ -404,8 +405,8 @@ WsLayout ws_layout(const mi355_unet* net, int B) {
 
 int64_t unet_workspace_bytes(const mi355_unet* net, int batch) { return (int64_t)ws_layout(net, batch).total; }
 
-int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int B,
-                 void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int B,
+                 void* workspace, int64_t workspace_bytes, hipStream_t stream, const UnetRun& run) {
   MI355_REQUIRE(net && x && t && out && workspace, -1, "unet_forward: null argument");
   MI355_REQUIRE(B > 0, -1, "unet_forward: batch must be positive");
   MI355_REQUIRE(Cx + (cond ? Cc : 0) == net->cfg.in_channels, -2, "unet_forward: x/cond channels do not add up to in_channels");
@@ -419,23 +420,21 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
   auto WF = [&](size_t off) { return reinterpret_cast<const float*>(W + off); };
   auto TP = [&](int id) -> void* { return id < 0 ? nullptr : ws + l.arena + net->tensors[id].offset_per_image * (size_t)B * esz; };
   int rc;
-  net->launches = 0;
   auto mark = [&](const mi355_op_profile& r) {
-    if (!net->prof) return;
+    if (!run.prof) return;
     hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, stream);
-    net->prof_events->push_back(e); net->prof->push_back(r);
+    run.prof_events->push_back(e); run.prof->push_back(r);
   };
-  if (net->prof) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, stream); net->prof_events->push_back(e); }
+  if (run.prof) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, stream); run.prof_events->push_back(e); }
   // time embedding path (fp32): emb2 = silu(time_embed(timestep_embedding(t))) ; embp = all emb_layers linears
   // in the sampler loops every image shares the step time: one embedding row, broadcast with stride 0
-  const int Be = net->t_uniform ? 1 : B, estride = net->t_uniform ? 0 : net->emb_total;
+  const int Be = run.t_uniform ? 1 : B, estride = run.t_uniform ? 0 : net->emb_total;
   if ((rc = timestep_embedding_launch(t, Be, mc, 10000.f, F(l.temb), stream))) return rc;
   if ((rc = linear_launch(F(l.temb), WF(net->te_w0), WF(net->te_b0), F(l.emb1), Be, mc, 4 * mc, 0, 1, stream))) return rc;
   if ((rc = linear_launch(F(l.emb1), WF(net->te_w2), WF(net->te_b2), F(l.emb2), Be, 4 * mc, 4 * mc, 0, 1, stream))) return rc;
   if ((rc = linear_launch(F(l.emb2), WF(net->emb_w), WF(net->emb_b), F(l.embp), Be, 4 * mc, net->emb_total, 0, 0, stream))) return rc;
   const int S = net->cfg.image_size;
   if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
-  net->launches += 5;
   { mi355_op_profile r{}; r.kind = MI355_OP_PRELUDE; mark(r); }
   for (const PlanOp& op : net->ops) {
     mi355_op_profile r{};
@@ -460,7 +459,7 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
       c.out_mode = op.out_mode;
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
       rc = conv_launch(c, stream);
-      if (net->prof) {
+      if (run.prof) {
         const ConvGeom cg = conv_geometry(c);
         const int cin = s0.C + C1;
         r.kind = MI355_OP_CONV; r.ks = op.ks; r.cin = cin; r.cout = op.Cout; r.h = cg.Ho; r.w = cg.Wo; r.tile_m = cg.BM; r.tile_n = cg.BN;
@@ -484,7 +483,6 @@ int unet_forward(mi355_unet* net, const float* x, int Cx, const float* cond, int
     }
     if (rc) return rc;
     mark(r);
-    ++net->launches;
   }
   return 0;
 }

@@ -71,6 +71,46 @@ class DDPM(nn.Module):
         reg("posterior_mean_coef2", (1.0 - alphas_cumprod_prev) * torch.sqrt(self.alphas) / (1.0 - alphas_cumprod))
         self._host = None
 
+    # ---- per-sample step arithmetic (sde_diffusion.py:214-244): `i` is a long [B] index tensor; the coefficient gather is
+    # `extract`, the multiply-adds are ONE fused HIP kernel (mi355_lincomb_per_sample) instead of 3-5 eager ones.  The samplers in
+    # image_diffusion.sampling use the scalar-coefficient step kernels; these methods serve callers that build their own
+    # x0_model closure (trainer2.py / loss_functions.py style). ----
+    @staticmethod
+    def _coef(table, i, x):
+        return extract(table, i.to(table.device), x.shape).reshape(-1).to(x.device, torch.float32).contiguous()
+
+    @staticmethod
+    def _lin(x, a, y=None, b=None):
+        from mi355.ops import default_ops
+
+        xs = x.float().contiguous()
+        return default_ops.lincomb_per_sample(xs, a, None if y is None else y.float().contiguous(), b)
+
+    def score_from_x0(self, x_0, i):
+        """sde_diffusion.py:214-217."""
+        return self._lin(x_0, -self._coef(self.recip_sqrt_m1_alphas_cumprod, i, x_0))
+
+    def predict_start_from_noise(self, x_i, i, noise):
+        """sde_diffusion.py:220-224."""
+        return self._lin(x_i, self._coef(self.sqrt_recip_alphas_cumprod, i, x_i), noise, -self._coef(self.sqrt_recipm1_alphas_cumprod, i, x_i))
+
+    def q_posterior(self, x0, x_i, i):
+        """sde_diffusion.py:226-233."""
+        mean = self._lin(x0, self._coef(self.posterior_mean_coef1, i, x_i), x_i, self._coef(self.posterior_mean_coef2, i, x_i))
+        return (mean, extract(self.posterior_variance, i.to(self.posterior_variance.device), x_i.shape).to(x_i.device),
+                extract(self.posterior_log_variance_clipped, i.to(self.posterior_variance.device), x_i.shape).to(x_i.device))
+
+    def p_mean_variance(self, x_start, x, i):
+        """sde_diffusion.py:235-237."""
+        model_mean, posterior_variance, posterior_log_variance = self.q_posterior(x0=x_start, x_i=x, i=i)
+        return model_mean, posterior_variance, posterior_log_variance, x_start
+
+    def q_sample(self, x_start, i):
+        """sde_diffusion.py:239-244: returns (x_i, noise); the draw is torch.randn_like, as in the reference."""
+        noise = torch.randn_like(x_start)
+        return self._lin(x_start, self._coef(self.sqrt_alphas_cumprod, i, x_start), noise,
+                         self._coef(self.sqrt_one_minus_alphas_cumprod, i, x_start)), noise
+
     def host_tables(self):
         """CPU fp32 copies of the buffers (per-step scalars are passed to the kernels by value)."""
         if self._host is None:

@@ -21,10 +21,6 @@ from mi355._lib import MI355BackendError
 from mi355.engine import UNetEngine
 
 
-def _heads_ok(cfg):
-    return True
-
-
 def param_shapes(cfg) -> "OrderedDict[str, tuple]":
     """Parameter names and shapes in the reference's state_dict order (unet.py:564-706).
 
@@ -176,11 +172,19 @@ class UNetModel(nn.Module):
             node.register_parameter(parts[-1], p)
         self._engine: Optional[UNetEngine] = None
         self._engine_key = None
+        self._weights_generation = 0
 
     # ---- engine management -------------------------------------------------------------------
     def set_precision(self, precision: str):
         """'bf16' (bf16 storage + bf16 MFMA, fp32 accumulate / GN / softmax) or 'fp32' (exact f32 MFMA)."""
         self.precision = precision
+        self._engine = None
+        return self
+
+    def invalidate_engine(self):
+        """The parameters were rewritten through a path autograd's version counters do not see (`.data.copy_`, a raw-pointer
+        kernel such as the fused EMA update): drop the packed copy so the next call re-packs the current values."""
+        self._weights_generation += 1
         self._engine = None
         return self
 
@@ -201,7 +205,8 @@ class UNetModel(nn.Module):
                 f"UNetModel.forward needs the model / inputs on an MI355X device (got {device}); this build has no CPU path")
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (str(device), self.precision, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        key = (str(device), self.precision, self._weights_generation, tuple(p._version for p in params),
+               tuple(p.data_ptr() for p in params))
         if self._engine is None or key != self._engine_key:
             self._engine = UNetEngine(self._cfg_kwargs(), self.state_dict(), device, self.precision)
             self._engine_key = key

@@ -75,7 +75,7 @@ SIGNATURES = {
     "mi355_unet_forward": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
     "mi355_unet_get_stats": (_I, [_VP, _I, C.POINTER(UNetStatsC)]),
     "mi355_unet_profile": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _I64, _VP, C.POINTER(OpProfileC), _I]),
-    "mi355_cfm_euler_sample": (_I, [_VP, _VP, _I, _VP, _I, _FP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
+    "mi355_cfm_euler_sample": (_I, [_VP, _VP, _I, _VP, _I, _I, _FP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
     "mi355_ddpm_sample": (_I, [_VP, _VP, _I, _VP, C.POINTER(DDPMTablesC), C.POINTER(DDPMOptionsC), _VP, _I64, _I, _VP, _I64, _VP]),
     "mi355_timestep_embedding": (_I, [_VP, _I, _I, _F, _VP, _VP]),
     "mi355_groupnorm": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _I, _VP]),
@@ -87,6 +87,7 @@ SIGNATURES = {
     "mi355_clip": (_I, [_VP, _F, _F, _I64, _VP]),
     "mi355_ema_update": (_I, [_VP, _VP, _F, _F, _I64, _VP]),
     "mi355_mse_per_sample": (_I, [_VP, _VP, _VP, C.c_int, _I64, _VP]),
+    "mi355_lincomb_per_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I64, _VP]),
     "mi355_quantize_u8": (_I, [_VP, _VP, _I64, _VP]),
     "mi355_to_unit_range": (_I, [_VP, _VP, _I64, _VP]),
     "mi355_randn": (_I, [_VP, _U64, _U64, _I64, _VP]),
@@ -94,7 +95,7 @@ SIGNATURES = {
     "mi355_rk_sqnorm": (_I, [_VP, _VP, _VP, _VP, _F, _F, _I64, _VP, _VP]),
     "mi355_rk_interp": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _I64, _VP]),
     "mi355_op_workspace_bytes": (_I64, [_I, _I, _I]),
-    "mi355_conv2d": (_I, [_VP, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP, _I64, _VP]),
+    "mi355_conv2d": (_I, [_VP, _VP, _I, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _I, _VP, _I64, _VP]),
     "mi355_qkv_attention": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I64, _VP]),
 }
 

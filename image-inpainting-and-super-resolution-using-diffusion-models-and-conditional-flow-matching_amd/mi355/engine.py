@@ -132,8 +132,10 @@ class UNetEngine:
                 "weight_bytes": s.weight_bytes}
 
     def cfm_euler(self, x: torch.Tensor, t_span: Sequence[float], cond: Optional[torch.Tensor] = None, keep_traj: bool = False,
-                  want_u8: bool = False):
-        """In-place Euler integration of x over t_span (host floats).  Returns (x, traj or None, u8 or None)."""
+                  want_u8: bool = False, cond_drift: bool = False):
+        """In-place Euler integration of x over t_span (host floats).  Returns (x, traj or None, u8 or None).
+        cond_drift: the condition is integrated with derivative `cond` (the concatenated-state sampler of
+        mnist/utils_mnist2.py:118-138); the caller's tensor is not modified."""
         B, Cx, Cc = self._split(x, cond)
         ts = [float(v) for v in t_span]
         arr = (C.c_float * len(ts))(*ts)
@@ -141,7 +143,7 @@ class UNetEngine:
         u8 = torch.empty(x.shape, device=self.device, dtype=torch.uint8) if want_u8 else None
         ws, wsb = self.workspace(B)
         check(self.L.mi355_cfm_euler_sample(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
-                                            Cc, arr, len(ts), self._chk(traj, "traj") if traj is not None else None,
+                                            Cc, int(bool(cond_drift)), arr, len(ts), self._chk(traj, "traj") if traj is not None else None,
                                             self._chk(u8, "u8", torch.uint8) if u8 is not None else None, B, ws, wsb, self._stream()),
               "mi355_cfm_euler_sample")
         return x, traj, u8

@@ -104,6 +104,20 @@ class Ops:
         check(_lib.lib().mi355_mse_per_sample(_req(a, "a"), _req(b, "b"), _req(out, "out"), a.shape[0], a[0].numel(), _stream()))
         return out
 
+    def lincomb_per_sample(self, x, a, y=None, b=None, out=None):
+        """out[n] = a[n] * x[n] (+ b[n] * y[n]) with per-sample fp32 device coefficients a, b of shape [B] (sde_diffusion.py:214-244)."""
+        B = x.shape[0]
+        if a.shape != (B,) or (b is not None and b.shape != (B,)):
+            raise ValueError("per-sample coefficients must have shape [B]")
+        if (y is None) != (b is None):
+            raise ValueError("y and b go together")
+        if y is not None:
+            _same(x, y, "x", "y")
+        out = torch.empty_like(x) if out is None else out
+        check(_lib.lib().mi355_lincomb_per_sample(_req(out, "out"), _req(x, "x"), _req(y, "y") if y is not None else None, _req(a, "a"),
+                                                  _req(b, "b") if b is not None else None, B, x[0].numel(), _stream()))
+        return out
+
     def quantize_u8(self, x):
         out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
         check(_lib.lib().mi355_quantize_u8(_req(x, "x"), _req(out, "out", torch.uint8), x.numel(), _stream()))
@@ -142,26 +156,39 @@ class Ops:
         return out
 
     # --- parity-test ops on NCHW fp32 tensors (pack -> MFMA kernel -> unpack) ---
-    def conv2d(self, x, weight, bias=None, stride=1, resample=0, gn=None, gn_silu=False, dtype=_lib.MI355_F32):
-        """weight/bias: CPU fp32 tensors in the reference layout [Co,Ci,k,k]; gn = (gamma, beta) device tensors."""
+    def conv2d(self, x, weight, bias=None, stride=1, resample=0, gn=None, gn_silu=False, dtype=_lib.MI355_F32, x1=None, emb=None,
+               res=None, res_mode=1):
+        """weight/bias: CPU fp32 tensors in the reference layout [Co,Ci(+Ci1),k,k]; gn = (gamma, beta) device tensors over the
+        (concatenated) input channels; x1: second source of a channel concat; emb [B, Co]; res [B, Co, Hr, Wr] with res_mode 1
+        (same size) or 2 (nearest x2 of a half-size tensor)."""
         B, Cin, H, W = x.shape
         Co, Ci, k, _ = weight.shape
-        assert Ci == Cin
+        Cin1 = 0 if x1 is None else x1.shape[1]
+        assert Ci == Cin + Cin1
+        if x1 is not None and (x1.shape[0] != B or x1.shape[2:] != x.shape[2:]):
+            raise ValueError("x1 must match x in batch and spatial size")
         Hc = H * 2 if resample == 2 else (H // 2 if resample == 3 else H)
         Wc = W * 2 if resample == 2 else (W // 2 if resample == 3 else W)
         Ho = (Hc + 2 * (k // 2) - k) // stride + 1
         Wo = (Wc + 2 * (k // 2) - k) // stride + 1
+        if emb is not None and emb.shape != (B, Co):
+            raise ValueError("emb must be [B, Co]")
+        if res is not None:
+            want = (B, Co, Ho, Wo) if res_mode == 1 else (B, Co, Ho // 2, Wo // 2)
+            if tuple(res.shape) != want:
+                raise ValueError(f"res must be {want}")
         y = torch.empty(B, Co, Ho, Wo, device=x.device, dtype=torch.float32)
         L = _lib.lib()
-        wsb = L.mi355_op_workspace_bytes(B, max(Cin, Co), max(H * W, Ho * Wo))
+        wsb = L.mi355_op_workspace_bytes(B, max(Ci, Co), max(H * W, Ho * Wo))
         ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
         w = weight.detach().to("cpu", torch.float32).contiguous()
         b = bias.detach().to("cpu", torch.float32).contiguous() if bias is not None else None
         fp = C.POINTER(C.c_float)
-        check(L.mi355_conv2d(_req(x, "x"), C.cast(w.data_ptr(), fp), C.cast(b.data_ptr(), fp) if b is not None else None,
-                             _req(y, "y"), B, Cin, H, W, Co, k, stride, resample,
-                             _req(gn[0], "gamma") if gn else None, _req(gn[1], "beta") if gn else None, int(gn_silu), dtype,
-                             C.c_void_p(ws.data_ptr()), wsb, _stream()), "mi355_conv2d")
+        check(L.mi355_conv2d(_req(x, "x"), _req(x1, "x1") if x1 is not None else None, Cin1, C.cast(w.data_ptr(), fp),
+                             C.cast(b.data_ptr(), fp) if b is not None else None, _req(y, "y"), B, Cin, H, W, Co, k, stride, resample,
+                             _req(gn[0], "gamma") if gn else None, _req(gn[1], "beta") if gn else None, int(gn_silu),
+                             _req(emb, "emb") if emb is not None else None, _req(res, "res") if res is not None else None, int(res_mode),
+                             dtype, C.c_void_p(ws.data_ptr()), wsb, _stream()), "mi355_conv2d")
         return y
 
     def qkv_attention(self, qkv, heads, new_order=False, dtype=_lib.MI355_F32):

@@ -41,8 +41,12 @@ class UNetModelWrapper(UNetModel):
         image_size = dim[-1]
         channel_mult = _default_mult(image_size) if channel_mult is None else tuple(channel_mult)
         attention_ds = tuple(image_size // int(res) for res in str(attention_resolutions).split(","))
-        if class_cond:
-            raise NotImplementedError("class-conditional sampling is not used by the reference's samplers")
+        # torchcfm: `num_classes = NUM_CLASSES if class_cond else None`-style gating - a label embedding exists only when a class
+        # count is given.  Every reference call site passes class_cond=True WITH num_classes=None (mnist/train_mnist.py:262-267,
+        # train_mnist2.py:350-355, train_mnist_hy.py:312-318, train_mnist_hy2.py:313-318), i.e. an unconditional network.
+        if class_cond and num_classes is not None:
+            raise NotImplementedError("class-conditional label_emb (class_cond=True with num_classes set) is not used by the "
+                                      "reference's samplers and is not built")
         super().__init__(image_size=image_size, in_channels=dim[0] if in_channels is None else in_channels,
                          model_channels=num_channels, out_channels=(dim[0] if not learn_sigma else dim[0] * 2),
                          num_res_blocks=num_res_blocks, attention_resolutions=attention_ds, dropout=dropout,
@@ -91,11 +95,11 @@ class SuperResModelWrapper(UNetModelWrapper):
 
 
 class NeuralODE:
-    """torchdyn.core.NeuralODE front-end, fixed-step Euler only (the adaptive dopri5 path is a 'next' row).
+    """torchdyn.core.NeuralODE front-end: solver="euler" (fixed step) or "dopri5" (adaptive, mi355.ode.Dopri5).
 
-    trajectory(x, t_span) -> Tensor[len(t_span), *x.shape].  When the vector field is a UNetModelWrapper the whole
-    integration runs inside libmi355_sampler (mi355_cfm_euler_sample); any other callable f(t, x[, args]) is driven
-    step by step from the host with the HIP Euler-update kernel."""
+    trajectory(x, t_span) -> Tensor[len(t_span), *x.shape].  Euler with a UNetModelWrapper vector field runs the whole
+    integration inside libmi355_sampler (mi355_cfm_euler_sample); any other callable f(t, x[, args]) is driven step by step from
+    the host with the HIP Euler-update kernel.  dopri5 is one continuous adaptive solve with dense output at the requested times."""
 
     def __init__(self, vector_field, solver="euler", sensitivity="adjoint", atol=1e-4, rtol=1e-4, **kwargs):
         if solver not in ("euler", "dopri5"):

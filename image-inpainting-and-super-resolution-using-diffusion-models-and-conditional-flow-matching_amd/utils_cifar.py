@@ -47,6 +47,11 @@ def ema(source, target, decay):
             default_ops.ema_update_(t, s, decay)
         else:
             t.copy_(t * decay + s * (1 - decay))
+    # neither path bumps the parameters' autograd version counters, which the packed-weight cache of UNetModel.engine() keys on:
+    # without this, `ema(net, ema_model, d); generate_samples(ema_model, ...)` (cifar10/train_cifar10.py:154-159) would sample
+    # from the weights packed at the first engine build
+    if hasattr(target, "invalidate_engine"):
+        target.invalidate_engine()
 
 
 def infiniteloop(dataloader):

@@ -1,12 +1,14 @@
-"""Drop-in for the reference's `mnist/utils_mnist*.py` sampler helpers, MI355X backend (fixed-step Euler).
+"""Drop-in for the reference's `mnist/utils_mnist.py` (imported by mnist/train_mnist.py:17), MI355X backend.
 
-Kept: get_random_patch / _sample / sample (utils_mnist.py:16-41), downsample_images (utils_mnist_hy.py:18-28),
-generate_samples (utils_mnist.py:45-73), generate_samples_eval in its Euler form (utils_mnist2.py:118-138, the
-active definition there: 999 Euler steps over linspace(0,1,1000), state = channel-concat [x, con]) for in-painting
-(`con=`) and its super-resolution sibling (`low_res=`, utils_mnist_hy.py:76-98), ema, infiniteloop.
-The reference's dopri5 variants (utils_mnist.py:90-134, utils_mnist_hy*.py) run on mi355.ode.Dopri5 (the torchdiffeq
-algorithm restated, HIP kernels for stage combination / error norm / dense output), including the tuple-state quirk;
-`solver="euler", steps=N` selects the fixed-step form.
+Same names and call contracts: get_random_patch / _sample / sample (utils_mnist.py:16-41, 14-pixel patch), generate_samples
+(:45-73, dopri5, 64 samples of 1x28x28, PNG grid), ema / infiniteloop (:76-88) and
+    generate_samples_eval(model, test_images, savedir, batch_size=8, step=0, net_="normal") -> (traj, con)     (:90-135)
+= torchdiffeq dopri5 (atol = rtol = 1e-4) over the TUPLE state (x, con).  The adaptive solver is mi355.ode (the torchdiffeq
+algorithm restated over HIP kernels: stage combination / error norm / dense output), including the tuple-state quirk.
+The sibling modules utils_mnist2 / utils_mnist_hy / utils_mnist_hy2 mirror the other three reference files (each has its own
+generate_samples_eval signature and return tuple); the shared sampler bodies live here (`_euler_conditional`,
+`_dopri5_conditional`).  Keyword-only extensions (`solver=`, `steps=`, `image_shape=`) select the other solver / a different
+state shape without changing the positional contract.
 """
 import torch
 import torch.nn.functional as F
@@ -26,16 +28,18 @@ def get_random_patch(image_size=28, patch_size=14):
     return h, w
 
 
-def _sample(images, pad_value=2, patch_size=14):
-    """images: [N, C, H, W] -> copy with a 14x14 patch set to -2 (utils_mnist.py:23-34; the arguments are
-    overridden inside the reference function, reproduced)."""
+def _sample_patch(images, patch_size):
     image_size = images.shape[-1]
-    pad_value = -2
-    patch_size = 14
     h, w = get_random_patch(image_size, patch_size)
     condition = images.detach().clone()
-    condition[:, :, h:h + patch_size, w:w + patch_size] = pad_value
+    condition[:, :, h:h + patch_size, w:w + patch_size] = -2
     return condition
+
+
+def _sample(images, pad_value=2, patch_size=14):
+    """images: [N, C, H, W] -> copy with a 14x14 patch set to -2 (utils_mnist.py:23-34; both arguments are
+    overridden inside the reference function - reproduced)."""
+    return _sample_patch(images, 14)
 
 
 def sample(x):
@@ -65,10 +69,14 @@ def generate_samples(model, parallel, savedir, step, net_="normal", solver="dopr
 
 
 def ema(source, target, decay):
+    """utils_mnist.py:76-82.  `.data.copy_` does not bump the autograd version counters the packed-weight cache keys on,
+    so the target's engine is invalidated explicitly."""
     source_dict = source.state_dict()
     target_dict = target.state_dict()
     for key in source_dict.keys():
         target_dict[key].data.copy_(target_dict[key].data * decay + source_dict[key].data * (1 - decay))
+    if hasattr(target, "invalidate_engine"):
+        target.invalidate_engine()
 
 
 def infiniteloop(dataloader):
@@ -77,20 +85,25 @@ def infiniteloop(dataloader):
             yield x
 
 
-def _euler_conditional(model, x_0, cond, steps):
-    """x_{k+1} = x_k + dt * model(x_k, t_k, cond); the condition is carried unchanged (utils_mnist2.py:120-124:
-    the concatenated state's second half has derivative `con` under torchdyn there, but only x[:,0] is read)."""
+def _euler_conditional(model, x_0, cond, steps, drift=True):
+    """Fixed-step Euler over the reference's CONCATENATED state [x, con] (utils_mnist2.py:118-138): ode_func returns
+    cat(model(x, t, con=con), con), so the second half's derivative is con itself and the condition the model is fed drifts,
+    con_{k+1} = con_k + dt * con_k (about e^t * con; the -2 sentinel reaches about -5.4).  Reproduced (drift=True); the
+    caller's `cond` tensor is not modified.  -> (x_1, nfe)"""
     ts = torch.linspace(0, 1, steps + 1).tolist()
     x = x_0.detach().clone().float().contiguous()
     if isinstance(model, (InPaintModelWrapper, SuperResModelWrapper)) and x.is_cuda:
         c = cond if isinstance(model, InPaintModelWrapper) else F.interpolate(cond, (x.shape[2], x.shape[3]), mode="bilinear")
-        model.engine(x.device).cfm_euler(x, ts, cond=c.float().contiguous())
+        model.engine(x.device).cfm_euler(x, ts, cond=c.float().contiguous(), cond_drift=drift)
         return x, steps
     kw = "con" if not isinstance(model, SuperResModelWrapper) else "low_res"
+    c = cond.detach().clone().float().contiguous()
     for k in range(steps):
         t = torch.tensor(ts[k], device=x.device)
-        v = model.forward(x, t, **{kw: cond})
+        v = model.forward(x, t, **{kw: c})
         default_ops.euler_step_(x, v.float().contiguous(), ts[k + 1] - ts[k])
+        if drift:
+            default_ops.euler_step_(c, c, ts[k + 1] - ts[k])
     return x, steps
 
 
@@ -108,35 +121,25 @@ def _dopri5_conditional(model, x_0, cond, kw):
     return x, nfe
 
 
-def generate_samples_eval(model, test_images, savedir=None, batch_size=8, step=0, net_="normal", solver="dopri5", steps=999):
-    """In-painting evaluation sampler: (traj, con, nfe).  solver="dopri5" is utils_mnist.py:90-134 (tuple state, adaptive);
-    solver="euler" is utils_mnist2.py:118-138 (999 Euler steps)."""
+def _eval_common(model, x_shape, cond, kw, solver, steps):
+    """Shared body of the four generate_samples_eval variants: x_0 ~ N(0, 1), integrate, clip(-1, 1).  -> (traj, nfe)"""
     _check_solver(solver)
     model.eval()
     with torch.no_grad():
-        con = sample(test_images).to(device)
-        x_0 = torch.randn(batch_size, *test_images.shape[1:], device=device)
+        x_0 = torch.randn(*x_shape, device=device)
         if solver == "dopri5":
-            x, nfe = _dopri5_conditional(model, x_0, con, "con")
+            x, nfe = _dopri5_conditional(model, x_0, cond, kw)
         else:
-            x, nfe = _euler_conditional(model, x_0, con.float().contiguous(), steps)
-        traj = default_ops.clip_(x.view([-1, *test_images.shape[1:]]).contiguous(), -1.0, 1.0)
+            x, nfe = _euler_conditional(model, x_0, cond.float().contiguous(), steps)
+        traj = default_ops.clip_(x.view([-1, *x_shape[1:]]).contiguous(), -1.0, 1.0)
     model.train()
-    return traj, con, nfe
+    return traj, nfe
 
 
-def generate_samples_eval_superres(model, test_images, batch_size=8, step=0, net_="normal", low_res_size=(16, 16), solver="dopri5",
-                                   steps=100):
-    """Super-resolution evaluation sampler (utils_mnist_hy.py:76-98, utils_mnist_hy2.py:148-169): (traj, low_res, nfe)."""
-    _check_solver(solver)
-    model.eval()
-    with torch.no_grad():
-        low_res = downsample_images(test_images, low_res_size).to(device)
-        x_0 = torch.randn(batch_size, *test_images.shape[1:], device=device)
-        if solver == "dopri5":
-            x, nfe = _dopri5_conditional(model, x_0, low_res, "low_res")
-        else:
-            x, nfe = _euler_conditional(model, x_0, low_res.float().contiguous(), steps)
-        traj = default_ops.clip_(x.view([-1, *test_images.shape[1:]]).contiguous(), -1.0, 1.0)
-    model.train()
-    return traj, low_res, nfe
+def generate_samples_eval(model, test_images, savedir, batch_size=8, step=0, net_="normal", *, solver="dopri5", steps=999,
+                          image_shape=(1, 28, 28)):
+    """utils_mnist.py:90-135: in-painting evaluation sampler, dopri5 over the tuple state (x, con); returns (traj, con) -
+    mnist/train_mnist.py:284,293,380 unpack exactly two values.  `savedir` is accepted and unused, as in the reference."""
+    con = sample(test_images).to(device)
+    traj, _ = _eval_common(model, (batch_size, *image_shape), con, "con", solver, steps)
+    return traj, con

@@ -120,7 +120,10 @@ int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const fl
  *  cifar10/utils_cifar.py:34-39, mnist/utils_mnist2.py:125-134).
  * x: in/out [B, Cx, H, W].  traj: NULL or [n_t, B, Cx, H, W] (all states, as the reference returns).
  * u8_out: NULL or uint8 [B, Cx, H, W] = (x*127.5+128).clip(0,255) (cifar10/compute_fid.py:87). */
-int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const float* cond, int cond_channels,
+/* cond_drift != 0: the condition is part of the integrated state with derivative `cond` itself, as in the reference's
+ * concatenated-state Euler sampler (mnist/utils_mnist2.py:118-138: ode_func returns cat(x_t, x[:,1])), i.e. the model sees
+ * cond_{k+1} = cond_k + dt*cond_k; the caller's `cond` tensor is left untouched (a scratch copy drifts). */
+int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const float* cond, int cond_channels, int cond_drift,
                            const float* t_span_host, int n_t, float* traj, uint8_t* u8_out, int batch,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
@@ -202,6 +205,11 @@ int mi355_ema_update(float* target, const float* source, float decay, float one_
 /* out[n] = mean over (C,H,W) of (a - b)^2: the per-sample MSE metric of the evaluation loop
  * (AD/experiments/main.py:299 `torch.mean((x0 - batch)**2, dim=(1, 2, 3))`) */
 int mi355_mse_per_sample(const float* a, const float* b, float* out, int batch, int64_t elems_per_sample, void* stream);
+/* out[n,:] = a[n]*x[n,:] + b[n]*y[n,:] with per-sample device coefficients a, b (y and b may both be NULL: out = a*x).
+ * The arithmetic of DDPM.predict_start_from_noise / q_posterior / q_sample / score_from_x0
+ * (AD/image_diffusion/sde_diffusion.py:214-244), whose coefficients are `extract`ed per sample (sde_diffusion.py:101-104). */
+int mi355_lincomb_per_sample(float* out, const float* x, const float* y, const float* a, const float* b, int batch,
+                             int64_t elems_per_sample, void* stream);
 /* (x*127.5+128).clip(0,255).to(uint8)  cifar10/compute_fid.py:87 */
 int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 /* x.clip(-1,1)/2 + 0.5  cifar10/utils_cifar.py:40-41 */
@@ -224,14 +232,18 @@ int mi355_rk_interp(float* out, const float* y0, const float* y1, const float* y
 /* Standalone conv / attention ops on NCHW fp32 tensors for parity tests of the HIP kernels
  * (pack -> implicit-GEMM MFMA kernel -> unpack; `workspace` from mi355_op_workspace_bytes). */
 int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw);
-/* Conv2d k in {1,3}, stride in {1,2}, padding k/2 - w_host [Co,Ci,k,k], bias_host [Co] are HOST pointers.
+/* Conv2d k in {1,3}, stride in {1,2}, padding k/2 - w_host [Co,Ci+Ci1,k,k], bias_host [Co] are HOST pointers.
+ * x1 (NULL or [B, cin1, H, W]): second source of a never-materialised channel concat th.cat([x, x1], 1) (unet.py:725).
  * resample: 0 none, 2 nearest x2 upsample of the input (unet.py:185-212), 3 2x2 average pool of the input.
- * Optional fused prologue GroupNorm32(gamma, beta) [+ SiLU] on the input (gn_gamma/gn_beta device
+ * Optional fused prologue GroupNorm32(gamma, beta) [+ SiLU] on the (concatenated) input (gn_gamma/gn_beta device
  * pointers or NULL), i.e. the ResBlock in_layers / out_layers (unet.py:283-286,306-311).
+ * Optional fused epilogue: + emb[B, Co] (ResBlock emb_layers, unet.py:349) and + res (NULL or [B, Co, Hr, Wr]; res_mode 1:
+ * Hr = Ho (skip + h, unet.py:351,401), 2: nearest x2 of a half-size tensor (ResBlock(up=True), unet.py:332-334)).
  * Synchronises the stream (test op: the packed weights are staged from a temporary host buffer). */
-int mi355_conv2d(const float* x, const float* w_host, const float* bias_host, float* y, int batch, int cin, int h, int w,
-                 int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
-                 int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
+                 int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
+                 const float* emb, const float* res, int res_mode, int dtype, void* workspace, int64_t workspace_bytes,
+                 void* stream);
 /* QKVAttentionLegacy / QKVAttention (unet.py:424-487): qkv [B, 3*H*ch, T] -> out [B, H*ch, T] */
 int mi355_qkv_attention(const float* qkv, float* out, int batch, int heads, int head_channels, int length, int new_order,
                         int dtype, void* workspace, int64_t workspace_bytes, void* stream);
