@@ -61,3 +61,26 @@ def randn(seed: int, *shape) -> torch.Tensor:
 def rand_uniform(seed: int, lo: float, hi: float, *shape) -> torch.Tensor:
     rs = np.random.RandomState(seed)
     return torch.from_numpy(rs.uniform(lo, hi, size=shape).astype(np.float32))
+
+
+def free_form_mask(seed: int, batch: int, height: int, width: int, coverage: float = 0.4, brush: int = 9) -> torch.Tensor:
+    """Seeded random-walk brush mask [batch, 1, H, W] (bool, True = masked) with about `coverage` of the pixels masked: the
+    "free-form mask" of BASELINE.json config 5 (the reference has no free-form mask generator; its masks are -2 sentinels at
+    arbitrary positions, likelihoods.py:55-56, so any boolean mask is admissible input - SURVEY 8 config reconciliation)."""
+    rs = np.random.RandomState(seed)
+    out = np.zeros((batch, 1, height, width), dtype=bool)
+    r = brush // 2
+    target = coverage * height * width
+    for b in range(batch):
+        y, x = int(rs.randint(0, height)), int(rs.randint(0, width))
+        ang = rs.uniform(0, 2 * np.pi)
+        m = out[b, 0]
+        while m.sum() < target:
+            m[max(0, y - r): y + r + 1, max(0, x - r): x + r + 1] = True
+            ang += rs.uniform(-0.6, 0.6)
+            step = rs.uniform(2, 6)
+            y = int(np.clip(y + step * np.sin(ang), 0, height - 1))
+            x = int(np.clip(x + step * np.cos(ang), 0, width - 1))
+            if rs.uniform() < 0.02:   # start a new stroke
+                y, x = int(rs.randint(0, height)), int(rs.randint(0, width))
+    return torch.from_numpy(out)

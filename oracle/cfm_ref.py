@@ -28,6 +28,20 @@ def euler_trajectory(f: Callable, x: torch.Tensor, t_span: torch.Tensor, keep_al
     return torch.stack(xs) if keep_all else x
 
 
+@torch.no_grad()
+def euler_concat_state(model: Callable, x0: torch.Tensor, con: torch.Tensor, t_span: torch.Tensor):
+    """mnist/utils_mnist2.py:118-138, restated: the ODE state is torch.cat((x, con), dim=1) and
+    ode_func(t, s) = cat(model(s_x, t, con=s_con), s_con) - the condition half's derivative is the condition itself, so under
+    fixed-step Euler the model is fed con_k = con * prod(1 + dt_j).  model(x, t, con) -> dx/dt.  Returns (x_final, con_final)."""
+    s = torch.cat((x0, con), dim=1)
+    C = x0.shape[1]
+    for k in range(len(t_span) - 1):
+        t, dt = t_span[k], t_span[k + 1] - t_span[k]
+        ds = torch.cat((model(s[:, :C], t, s[:, C:]), s[:, C:]), dim=1)
+        s = s + dt * ds
+    return s[:, :C], s[:, C:]
+
+
 def to_uint8(x: torch.Tensor) -> torch.Tensor:
     """cifar10/compute_fid.py:87: (x*127.5 + 128).clip(0, 255).to(uint8)  (truncation toward zero)."""
     return (x * 127.5 + 128).clip(0, 255).to(torch.uint8)

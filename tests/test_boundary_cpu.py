@@ -1,6 +1,8 @@
 """CPU: the drop-in boundary against the reference's REAL call sites (constructor kwargs, module names, signatures, return
 tuples, checkpoint layouts, rank-consistent x0 draws).  No compute runs here (no GPU): these tests pin the host logic."""
 import inspect
+
+import numpy as np
 import os
 import subprocess
 import sys
@@ -230,3 +232,39 @@ def test_compute_fid_x0_is_the_one_rank_batch_resharded(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_local_writer_files(tmp_path):
+    """AD/image_diffusion/writers.py:291-369 (LocalWriter): metrics.csv (pandas frame, flushed every n and on close, the index
+    column restarting at every flush like the reference's read-concat-write), config.yaml, images/<key>_<step>.png."""
+    import pandas as pd
+    import yaml
+    from PIL import Image
+
+    from image_diffusion.writers import LocalWriter
+
+    w = LocalWriter(str(tmp_path / "run"), flush_every_n=2)
+    w.log_hparams({"lr": 1e-3, "net": {"num_channels": 32}})
+    assert yaml.safe_load(open(tmp_path / "run" / "config.yaml")) == {"lr": 1e-3, "net": {"num_channels": 32}}
+    w.write_scalars(0, {"loss": 1.5})
+    assert not (tmp_path / "run" / "metrics.csv").exists()            # not flushed yet
+    w.write_scalars(1, {"loss": 1.25})
+    df = pd.read_csv(tmp_path / "run" / "metrics.csv", index_col=0)
+    assert list(df.columns) == ["step", "loss"] and df["loss"].tolist() == [1.5, 1.25] and df.index.tolist() == [0, 1]
+    w.write_scalars(2, {"loss": 1.0, "test_conditional_mse": 0.3})   # mnist/train_mnist.py:283-288
+    w.close()
+    df = pd.read_csv(tmp_path / "run" / "metrics.csv", index_col=0)
+    assert df["step"].tolist() == [0, 1, 2] and df.index.tolist() == [0, 1, 0]
+    assert np.isnan(df["test_conditional_mse"].iloc[0]) and df["test_conditional_mse"].iloc[2] == 0.3
+    w.write_images(7, {"samples": torch.rand(6, 1, 8, 8), "one": (torch.rand(3, 5, 4) * 255).to(torch.uint8)})
+    g = Image.open(tmp_path / "run" / "images" / "samples_7.png")
+    assert g.size == (6 * 10 + 2, 10 + 2)                              # make_grid: nrow 8, padding 2
+    assert Image.open(tmp_path / "run" / "images" / "one_7.png").size == (4, 5)
+
+    class Fig:
+        def savefig(self, path, bbox_inches=None):
+            assert bbox_inches == "tight"
+            open(path, "wb").write(b"png")
+
+    w.write_figures(9, {"condition": Fig()})
+    assert (tmp_path / "run" / "images" / "condition_9.png").exists()

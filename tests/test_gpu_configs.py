@@ -1,0 +1,451 @@
+"""GPU parity at BENCH-SIZED batches and on the BASELINE configs that had never run as samplers (tasks 1 and 2c).
+
+Per-sample independence (GroupNorm and attention are per image: test_batch_independence_and_large_batch) makes a real check of a
+large batch cheap: run the whole batch on the GPU - so the large-tile / warp-specialised persistent kernels are the ones that
+run - and run the CPU oracle on a few images of that batch.
+
+Tolerances (stated): fp32 mode = the whole-forward tolerance of test_gpu_unet (rtol 2e-4 / atol 5e-5), loosened with the number
+of sequential network calls as written at each test; bf16 mode = bounded relative to the output scale and reported.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mi355 import _lib
+from mi355.synth import free_form_mask, rand_uniform, randn, synth_state_dict
+from oracle import cfm_ref, ddpm_ref, unet_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CIFAR = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+             channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
+
+
+def _net(kw, seed, precision):
+    from image_diffusion.unet import UNetModel, param_shapes
+
+    net = UNetModel(precision=precision, **kw)
+    sd = synth_state_dict(param_shapes(net), seed)
+    net.load_state_dict(sd)
+    return net.to(DEV), sd
+
+
+def _cfg(kw):
+    return unet_ref.UNetConfig(kw["image_size"], kw["in_channels"], kw["model_channels"], kw["out_channels"], kw["num_res_blocks"],
+                               kw["attention_resolutions"], channel_mult=kw["channel_mult"], num_heads=kw.get("num_heads", 1),
+                               num_head_channels=kw.get("num_head_channels", -1), use_scale_shift_norm=kw.get("use_scale_shift_norm", False),
+                               resblock_updown=kw.get("resblock_updown", False))
+
+
+def _report(tag, got, ref):
+    err = (got - ref).abs()
+    scale = ref.abs().max().item()
+    rms = err.pow(2).mean().sqrt().item() / max(ref.pow(2).mean().sqrt().item(), 1e-12)
+    print(f"{tag}: max|err| {err.max().item():.3e} (scale {scale:.3f}), rel rms {rms:.3e}")
+    return err.max().item(), scale, rms
+
+
+# ---- (a) cfg 2 at the bench batch ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg2_b256_forward_and_euler_vs_oracle(precision):
+    """BASELINE configs[1] at B = 256 (the measured configuration): every conv of the 32x32 and 16x16 levels takes
+    conv3x3_ws_kernel here (two-source concat, RES_SAME residual, emb-initialised accumulators included) - compared with the CPU
+    oracle on images {0, 131, 255}: one forward with per-sample t, and a 3-step Euler trajectory."""
+    net, sd = _net(CIFAR, 1234, precision)
+    cfg = _cfg(CIFAR)
+    B, pick = 256, [0, 131, 255]
+    x = randn(4242, B, 3, 32, 32)
+    t = torch.linspace(0.0, 1.0, B)
+    y = net(x.to(DEV), t.to(DEV)).cpu()
+    ref = unet_ref.unet_forward(sd, cfg, x[pick], t[pick])
+    emax, scale, rms = _report(f"cfg2 B=256 forward {precision}", y[pick], ref)
+    if precision == "fp32":
+        torch.testing.assert_close(y[pick], ref, rtol=2e-4, atol=5e-5)
+    else:
+        assert emax < 0.04 * scale and rms < 0.02
+    ts = torch.linspace(0, 1, 4)
+    f = unet_ref.model_fn(sd, cfg)
+    xr = cfm_ref.euler_trajectory(f, x[pick], ts, keep_all=False)
+    xg = x.to(DEV).clone()
+    net.engine(DEV).cfm_euler(xg, ts.tolist())
+    emax, scale, rms = _report(f"cfg2 B=256 3-step Euler {precision}", xg.cpu()[pick], xr)
+    if precision == "fp32":
+        torch.testing.assert_close(xg.cpu()[pick], xr, rtol=5e-4, atol=1e-4)
+    else:
+        assert emax < 0.03 * scale and rms < 0.01
+
+
+# ---- (b) the persistent conv's concat / residual / emb paths at op level ---------------------------------------------------------
+
+WS_CASES = [
+    # B, C0, C1, H, Cout, resample, gn+silu, emb, res_mode      (all >= 512 workgroups of 128 x 128 => conv3x3_ws_kernel)
+    (128, 256, 128, 16, 256, 0, True, True, 0),    # output_blocks ResBlock in_layers: GN(cat(h, skip)) + SiLU, conv, + emb
+    (128, 256, 256, 16, 256, 0, True, True, 0),    # 512 -> 256 @ 16x16
+    (128, 256, 0, 16, 256, 0, True, False, 1),     # ResBlock out_layers: GN + SiLU, conv, + skip (RES_SAME)
+    (64, 128, 128, 32, 128, 0, True, True, 1),     # everything at once at 32x32
+    (64, 128, 0, 32, 128, 0, True, False, 2),      # ResBlock(up=True) out_layers: residual = nearest x2 of the half-size x (RES_UP2)
+    (64, 128, 0, 16, 128, 2, True, True, 0),       # ResBlock(up=True) in_layers: conv over nearest x2 of SiLU(GN(x)), + emb
+    (64, 128, 0, 32, 256, 0, False, True, 1),      # no prologue, two channel tiles, emb + residual
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+@pytest.mark.parametrize("dtype,rtol,atol", [(_lib.MI355_F32, 5e-5, 5e-5), (_lib.MI355_BF16, 3e-2, 3e-2)])
+def test_ws_conv_concat_residual_emb(case, dtype, rtol, atol):
+    from mi355.ops import default_ops as ops
+
+    B, C0, C1, H, Co, resample, gn, use_emb, res_mode = case
+    seed = 7000 + hash(case) % 1000
+    x = randn(seed, B, C0, H, H) * 1.3 + 0.1
+    x1 = randn(seed + 1, B, C1, H, H) * 0.7 - 0.2 if C1 else None
+    C = C0 + C1
+    sd = synth_state_dict({"in_layers.0.weight": (C,), "in_layers.0.bias": (C,), "weight": (Co, C, 3, 3), "bias": (Co,)}, seed + 2)
+    Ho = 2 * H if resample == 2 else H
+    emb = randn(seed + 3, B, Co) * 0.5 if use_emb else None
+    res = None
+    if res_mode == 1:
+        res = randn(seed + 4, B, Co, Ho, Ho)
+    elif res_mode == 2:
+        res = randn(seed + 4, B, Co, Ho // 2, Ho // 2)
+    xin = x if x1 is None else torch.cat((x, x1), dim=1)          # th.cat([h, hs.pop()], dim=1)  unet.py:725
+    h = xin
+    if gn:
+        h = F.silu(unet_ref.group_norm32(h, sd["in_layers.0.weight"], sd["in_layers.0.bias"]))
+    if resample == 2:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, sd["weight"], sd["bias"], padding=1)
+    if emb is not None:
+        ref = ref + emb[:, :, None, None]
+    if res_mode == 1:
+        ref = ref + res
+    elif res_mode == 2:
+        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+    got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], resample=resample,
+                     gn=(sd["in_layers.0.weight"].to(DEV), sd["in_layers.0.bias"].to(DEV)) if gn else None, gn_silu=gn, dtype=dtype,
+                     x1=x1.to(DEV) if x1 is not None else None, emb=emb.to(DEV) if emb is not None else None,
+                     res=res.to(DEV) if res is not None else None, res_mode=res_mode or 1).cpu()
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
+
+
+def test_small_tile_conv_concat_residual_emb_fp32():
+    """The same epilogue / two-source paths on the plain (non-persistent) kernels: small batches, 8x8 multi-image tiles, 1x1."""
+    from mi355.ops import default_ops as ops
+
+    for (B, C0, C1, H, Co, k) in [(3, 64, 32, 16, 64, 3), (5, 64, 64, 8, 128, 3), (4, 64, 32, 16, 128, 1), (9, 32, 32, 4, 64, 3)]:
+        x, x1 = randn(C0 + H, B, C0, H, H), randn(C1 + H + 1, B, C1, H, H)
+        C = C0 + C1
+        sd = synth_state_dict({"in_layers.0.weight": (C,), "in_layers.0.bias": (C,), "weight": (Co, C, k, k), "bias": (Co,)}, C + k)
+        emb, res = randn(5, B, Co), randn(6, B, Co, H, H)
+        h = F.silu(unet_ref.group_norm32(torch.cat((x, x1), 1), sd["in_layers.0.weight"], sd["in_layers.0.bias"]))
+        ref = F.conv2d(h, sd["weight"], sd["bias"], padding=k // 2) + emb[:, :, None, None] + res
+        got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], gn=(sd["in_layers.0.weight"].to(DEV), sd["in_layers.0.bias"].to(DEV)),
+                         gn_silu=True, x1=x1.to(DEV), emb=emb.to(DEV), res=res.to(DEV), res_mode=1).cpu()
+        torch.testing.assert_close(got, ref, rtol=5e-5, atol=5e-5)
+
+
+# ---- (c) cfg 3 at its batch --------------------------------------------------------------------------------------------------
+
+def test_cfg3_b512_amortized_ddpm_vs_oracle():
+    """BASELINE config 3 at B = 512: CIFAR U-Net with in_channels = 6, centred 16x16 block = -2, Amortized DDPM ancestral sampler.
+    Ns = 25 (the first few steps have x0-predictor gains of 2e3, the hard part) with injected noise; fp32 engine vs the CPU oracle on
+    images {0, 511}; then the same run in bf16 bounded against the fp32 result."""
+    from image_diffusion import sampling
+    from image_diffusion.conditioning import Amortized
+    from image_diffusion.likelihoods import InPainting
+    from image_diffusion.sde_diffusion import DDPM
+
+    Ns, B, pick = 25, 512, [0, 511]
+    kw = dict(CIFAR, in_channels=6)
+    net, sd = _net(kw, 1235, "fp32")
+    cfg = _cfg(kw)
+    ddpm = DDPM(Ns)
+    g = torch.Generator().manual_seed(99)
+    xT = torch.randn(B, 3, 32, 32, generator=g)
+    cond = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    cond[:, :, 8:24, 8:24] = -2.0
+    zs = torch.randn(Ns - 1, B, 3, 32, 32, generator=g)
+    it = iter([z[pick] for z in zs])
+    ref = ddpm_ref.amortized_sample(ddpm_ref.make_eps_model(lambda x, t: unet_ref.unet_forward(sd, cfg, x, t), Ns), Ns, xT[pick], cond[pick],
+                                    lambda shape: next(it))
+    fn = sampling.get_conditional_sample_fn(sampling.make_eps_model(net, ddpm), ddpm, Amortized(0.9, 0, 0.1), InPainting(16, -2))
+    with sampling.injected_noise(zs):
+        got32 = fn(xT.to(DEV), cond.to(DEV)).cpu()
+    _report("cfg3 B=512 Ns=25 fp32", got32[pick], ref)
+    torch.testing.assert_close(got32[pick], ref, rtol=5e-3, atol=3e-3)
+    net.set_precision("bf16")
+    fn = sampling.get_conditional_sample_fn(sampling.make_eps_model(net, ddpm), ddpm, Amortized(0.9, 0, 0.1), InPainting(16, -2))
+    with sampling.injected_noise(zs):
+        got16 = fn(xT.to(DEV), cond.to(DEV)).cpu()
+    emax, _, rms = _report("cfg3 B=512 Ns=25 bf16 vs fp32", got16, got32)
+    assert torch.isfinite(got16).all() and rms < 0.05 and (got16 - got32).abs().mean() < 0.02
+    # the device-Philox path (the throughput configuration) runs and is deterministic in the seed
+    torch.manual_seed(5)
+    a = fn(xT.to(DEV), cond.to(DEV))
+    torch.manual_seed(5)
+    sampling._draw_counter = 0
+    assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0
+
+
+# ---- (d) cfg 5: 128 px, attention at 32 / 16 / 8, free-form mask -----------------------------------------------------------------
+
+PX128 = dict(image_size=128, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(4, 8, 16),
+             channel_mult=(1, 1, 2, 3, 4), num_heads=4, num_head_channels=64)
+
+
+def test_cfg5_px128_freeform_amortized_ddpm_and_ddim_vs_oracle():
+    """BASELINE config 5 geometry at FULL width (mc = 128, 74.6 M parameters; attention at 32x32 / 16x16 / 8x8 = T 1024 / 256 / 64),
+    in = 6 = x || condition, condition = image with a seeded free-form (random-walk brush) mask set to -2: the Amortized DDPM
+    ancestral sampler and the DDIM extension, Ns = 21 (the shortest finite schedule), B = 1, fp32 engine vs the fp32 CPU oracle;
+    then bf16 bounded against fp32."""
+    from image_diffusion import sampling
+    from image_diffusion.conditioning import Amortized
+    from image_diffusion.likelihoods import InPainting
+    from image_diffusion.sde_diffusion import DDPM
+
+    Ns, B = 21, 1
+    net, sd = _net(PX128, 1237, "fp32")
+    cfg = _cfg(PX128)
+    ddpm = DDPM(Ns)
+    xT = randn(920, B, 3, 128, 128)
+    cond = rand_uniform(921, -1.0, 1.0, B, 3, 128, 128)
+    mask = free_form_mask(922, B, 128, 128, 0.4)
+    cond = torch.where(mask.expand_as(cond), torch.full_like(cond, -2.0), cond)
+    assert 0.35 < float((cond == -2).float().mean()) < 0.45
+    zs = [randn(2000 + j, B, 3, 128, 128) for j in range(Ns - 1)]
+    eps_ref = ddpm_ref.make_eps_model(lambda x, t: unet_ref.unet_forward(sd, cfg, x, t), Ns)
+    it = iter(zs)
+    ref = ddpm_ref.amortized_sample(eps_ref, Ns, xT, cond, lambda shape: next(it))
+    eps = sampling.make_eps_model(net, ddpm)
+    lik = InPainting(16, -2)
+    with sampling.injected_noise(zs):
+        got = sampling.get_conditional_sample_fn(eps, ddpm, Amortized(0.9, 0, 0.1), lik)(xT.to(DEV), cond.to(DEV)).cpu()
+    _report("cfg5 128px amortized DDPM Ns=21 fp32", got, ref)
+    torch.testing.assert_close(got, ref, rtol=5e-3, atol=3e-3)
+    ref_ddim = ddpm_ref.ddim_sample(eps_ref, Ns, xT, cond)
+    got_ddim = sampling.get_ddim_sample_fn(eps, ddpm, lik)(xT.to(DEV), cond.to(DEV)).cpu()
+    _report("cfg5 128px DDIM Ns=21 fp32", got_ddim, ref_ddim)
+    torch.testing.assert_close(got_ddim, ref_ddim, rtol=5e-3, atol=3e-3)
+    net.set_precision("bf16")
+    eps = sampling.make_eps_model(net, ddpm)
+    got16 = sampling.get_ddim_sample_fn(eps, ddpm, lik)(xT.to(DEV), cond.to(DEV)).cpu()
+    emax, _, rms = _report("cfg5 128px DDIM Ns=21 bf16 vs fp32 oracle", got16, ref_ddim)
+    assert torch.isfinite(got16).all() and rms < 0.05
+
+
+# ---- (e) cfg 1: the MNIST net through the sampler loops ---------------------------------------------------------------------------
+
+MNIST = dict(image_size=28, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=(1,),
+             channel_mult=(1, 2, 2), resblock_updown=True)   # AD/experiments/config.py:101-107 through create_model (ds = 28 // 16 = 1)
+
+
+def test_cfg1_mnist_prior_ddpm_b64_and_ns20_nan(tmp_path):
+    """BASELINE config 1 as SURVEY reconciles it: the MNIST net (attention at 28x28, T = 784) through get_prior_sample_fn at
+    Ns = 25, B = 64 (value parity on images {0, 63}), Ns = 20 => all-NaN like the reference (finding 4), and 20-step CFM Euler
+    through utils_mnist.generate_samples (B = 64, PNG grid)."""
+    from PIL import Image
+
+    import utils_mnist
+    from image_diffusion import sampling
+    from image_diffusion.conditioning import Replacement
+    from image_diffusion.likelihoods import InPainting
+    from image_diffusion.sde_diffusion import DDPM
+    from image_diffusion.unet import create_model, param_shapes
+
+    net = create_model(image_size=28, in_channels=1, out_channels=1, num_channels=32, num_res_blocks=1, channel_mult="1, 2, 2",
+                       resblock_updown=True)
+    assert net.attention_resolutions == (1,)
+    net.set_precision("fp32")
+    sd = synth_state_dict(param_shapes(net), 1238)
+    net.load_state_dict(sd)
+    net.to(DEV)
+    cfg = _cfg(MNIST)
+    Ns, B, pick = 25, 64, [0, 63]
+    ddpm = DDPM(Ns)
+    g = torch.Generator().manual_seed(17)
+    xT = torch.randn(B, 1, 28, 28, generator=g)
+    zs = torch.randn(Ns - 1, B, 1, 28, 28, generator=g)
+    it = iter([z[pick] for z in zs])
+    ref = ddpm_ref.prior_sample(ddpm_ref.make_eps_model(lambda x, t: unet_ref.unet_forward(sd, cfg, x, t), Ns), Ns, xT[pick], lambda s: next(it))
+    fn = sampling.get_prior_sample_fn(sampling.make_eps_model(net, ddpm), ddpm, Replacement(0.1, 1.0, True, 0), InPainting(14, -2))
+    with sampling.injected_noise(zs):
+        got = fn(xT.to(DEV)).cpu()
+    _report("cfg1 MNIST prior DDPM Ns=25 B=64", got[pick], ref)
+    torch.testing.assert_close(got[pick], ref, rtol=2e-3, atol=1e-3)
+    ddpm20 = DDPM(20)
+    x20 = sampling.get_prior_sample_fn(sampling.make_eps_model(net, ddpm20), ddpm20, Replacement(0.1, 1.0, True, 0), InPainting(14, -2))(xT.to(DEV))
+    assert torch.isnan(x20).all()
+    # 20-step CFM Euler through utils_mnist.generate_samples: the torchcfm-convention wrapper around the same architecture
+    from torchcfm_compat import NeuralODE, UNetModelWrapper
+
+    w = UNetModelWrapper(dim=(1, 28, 28), num_channels=32, num_res_blocks=1, num_classes=None, class_cond=True, precision="fp32")
+    wsd = synth_state_dict(param_shapes(w), 1239)
+    w.load_state_dict(wsd)
+    w.to(DEV)
+    w.train()
+    utils_mnist.generate_samples(w, False, str(tmp_path) + "/", 20, net_="normal", solver="euler", steps=20)
+    assert w.training
+    img = Image.open(tmp_path / "normal_generated_FM_images_step_20.png")
+    assert img.size == (8 * 30 + 2, 8 * 30 + 2)
+    wcfg = unet_ref.UNetConfig(28, 1, 32, 1, 1, (1,), channel_mult=(1, 2, 2))
+    x0 = randn(31, B, 1, 28, 28)
+    traj = NeuralODE(w, solver="euler").trajectory(x0.to(DEV), torch.linspace(0, 1, 21))
+    refx = cfm_ref.euler_trajectory(unet_ref.model_fn(wsd, wcfg), x0[pick], torch.linspace(0, 1, 21), keep_all=False)
+    _report("cfg1 MNIST 20-step Euler B=64", traj[-1].cpu()[pick], refx)
+    torch.testing.assert_close(traj[-1].cpu()[pick], refx, rtol=2e-3, atol=5e-4)
+
+
+# ---- 2(c): generate_samples_eval / gen_1_img / checkpoints / ema on the device ------------------------------------------------------
+
+def _inpaint_pair(seed, precision="fp32", dim=(1, 28, 28), **extra):
+    from image_diffusion.unet import param_shapes
+    from torchcfm_compat import InPaintModelWrapper
+
+    m = InPaintModelWrapper(dim=dim, num_channels=32, num_res_blocks=1, num_classes=None, class_cond=True, precision=precision, **extra)
+    sd = synth_state_dict(param_shapes(m), seed)
+    m.load_state_dict(sd)
+    cfg = unet_ref.UNetConfig(dim[-1], 2 * dim[0], 32, dim[0], 1, (1,), channel_mult=(1, 2, 2))
+    return m.to(DEV), sd, cfg
+
+
+def test_generate_samples_eval_euler_vs_oracle():
+    """utils_mnist2.generate_samples_eval (mnist/utils_mnist2.py:118-138: Euler over the concatenated state, the condition drifts)
+    against oracle/cfm_ref.euler_concat_state with the same x_0 / mask draws; 64x64 images (a 20-pixel patch does not fit 28)."""
+    import utils_mnist2
+
+    m, sd, cfg = _inpaint_pair(1240, dim=(1, 64, 64), num_head_channels=32)
+    cfg = unet_ref.UNetConfig(64, 2, 32, 1, 1, (4,), channel_mult=(1, 2, 3, 4), num_head_channels=32)   # _default_mult(64), "16" -> ds 4
+    imgs = rand_uniform(41, -1, 1, 4, 1, 64, 64).to(DEV)
+    steps = 12
+    torch.manual_seed(123)
+    traj, con, nfe = utils_mnist2.generate_samples_eval(m, imgs, batch_size=4, steps=steps, image_shape=(1, 64, 64))
+    assert nfe == steps and traj.shape == (4, 1, 64, 64) and int((con == -2).sum()) == 4 * 400
+    torch.manual_seed(123)
+    con2 = utils_mnist2.sample(imgs).to(DEV)          # same CPU randint stream ...
+    x0 = torch.randn(4, 1, 64, 64, device=DEV)        # ... and the same device randn stream as inside the call
+    assert torch.equal(con2, con)
+    model = lambda x, t, c: unet_ref.unet_forward(sd, cfg, torch.cat((x, c), dim=1), t.repeat(x.shape[0]))
+    xr, cr = cfm_ref.euler_concat_state(model, x0.cpu(), con.cpu(), torch.linspace(0, 1, steps + 1))
+    _report("generate_samples_eval (Euler, drifting condition)", traj.cpu(), xr.clip(-1, 1))
+    torch.testing.assert_close(traj.cpu(), xr.clip(-1, 1), rtol=2e-3, atol=5e-4)
+    assert float(cr.min()) < -5.0   # the -2 sentinel has drifted to about -2 e (what the model was fed at the end)
+
+
+def test_generate_samples_eval_dopri5_tuple_state_vs_restatement():
+    """utils_mnist.generate_samples_eval (mnist/utils_mnist.py:90-135, dopri5 over the tuple state) and the super-resolution form
+    (utils_mnist_hy2.py:148-169) against oracle/cfm_ref.dopri5 - 'parity unpinned' (torchdiffeq is not vendored)."""
+    import utils_mnist
+    import utils_mnist_hy2
+    from image_diffusion.unet import param_shapes
+    from torchcfm_compat import SuperResModelWrapper
+
+    m, sd, cfg = _inpaint_pair(1241)
+    imgs = rand_uniform(43, -1, 1, 3, 1, 28, 28).to(DEV)
+    torch.manual_seed(7)
+    traj, con = utils_mnist.generate_samples_eval(m, imgs, "/unused/", batch_size=3)
+    torch.manual_seed(7)
+    con2 = utils_mnist.sample(imgs).to(DEV)
+    x0 = torch.randn(3, 1, 28, 28, device=DEV)
+    assert torch.equal(con2, con)
+    f = lambda t, st: (unet_ref.unet_forward(sd, cfg, torch.cat((st[0], st[1]), dim=1), t.reshape(1).repeat(3)), st[1])
+    (xr, _), nfe_ref = cfm_ref.dopri5(f, (x0.cpu(), con.cpu()), 0.0, 1.0, 1e-4, 1e-4)
+    _report("generate_samples_eval (dopri5 tuple state)", traj.cpu(), xr.clip(-1, 1))
+    torch.testing.assert_close(traj.cpu(), xr.clip(-1, 1), rtol=3e-3, atol=3e-3)
+    s = SuperResModelWrapper(dim=(1, 28, 28), num_channels=32, num_res_blocks=1, num_classes=None, class_cond=True, precision="fp32")
+    ssd = synth_state_dict(param_shapes(s), 1242)
+    s.load_state_dict(ssd)
+    s.to(DEV)
+    torch.manual_seed(8)
+    traj, low, nfe = utils_mnist_hy2.generate_samples_eval(s, imgs, batch_size=3)
+    assert low.shape == (3, 1, 7, 7) and nfe > 0
+    torch.manual_seed(8)
+    x0 = torch.randn(3, 1, 28, 28, device=DEV)
+    scfg = unet_ref.UNetConfig(28, 2, 32, 1, 1, (1,), channel_mult=(1, 2, 2))
+    fs = lambda t, st: (unet_ref.unet_forward(ssd, scfg, torch.cat((st[0], F.interpolate(st[1], (28, 28), mode="bilinear")), dim=1),
+                                              t.reshape(1).repeat(3)), st[1])
+    (xr, _), _ = cfm_ref.dopri5(fs, (x0.cpu(), low.cpu()), 0.0, 1.0, 1e-4, 1e-4)
+    torch.testing.assert_close(traj.cpu(), xr.clip(-1, 1), rtol=3e-3, atol=3e-3)
+
+
+def test_make_gen_1_img_u8_vs_oracle():
+    """cifar10/compute_fid.py:73-88 drop-in: uint8 [B, 3, 32, 32] from a seeded x0, against oracle gen_images_u8 (+-1 code value)."""
+    import compute_fid
+
+    net = compute_fid.build_model(128, DEV, precision="fp32")
+    from image_diffusion.unet import param_shapes
+    sd = synth_state_dict(param_shapes(net), 1234)
+    net.load_state_dict(sd)
+    B, steps, pick = 40, 8, [0, 17, 39]
+    gen = compute_fid.make_gen_1_img(net, batch_size_fid=B, integration_steps=steps, integration_method="euler", device=DEV, seed=11)
+    img = gen(None)
+    assert img.dtype == torch.uint8 and img.shape == (B, 3, 32, 32) and img.device.type == "cuda"
+    x0 = compute_fid.draw_x0_shard(B, 11, 0, torch.device(DEV)).cpu()
+    ref = cfm_ref.gen_images_u8(unet_ref.model_fn(sd, _cfg(CIFAR)), x0[pick], steps)
+    d = (img.cpu()[pick].int() - ref.int()).abs()
+    print(f"gen_1_img: max code diff {int(d.max())}, differing {float((d > 0).float().mean()):.4f}")
+    assert int(d.max()) <= 1
+    img2 = gen(None)                       # the next call draws a fresh batch (call index is part of the seed)
+    assert not torch.equal(img2, img)
+
+
+def test_checkpoint_load_then_forward_and_ema_then_sample(tmp_path):
+    """A checkpoint in the torchcfm layout is read with weights_only=True and drives the HIP engine; ema() followed by a forward
+    uses the UPDATED weights (the packed-weight cache used to go stale)."""
+    import compute_fid
+    import utils_cifar
+    from image_diffusion.unet import param_shapes
+    from torchcfm_compat import UNetModelWrapper
+
+    kw = dict(dim=(3, 16, 16), num_channels=32, num_res_blocks=1, channel_mult=(1, 2), num_heads=2, attention_resolutions="8", precision="fp32")
+    donor = UNetModelWrapper(**kw)
+    sd = synth_state_dict(param_shapes(donor), 1003)
+    donor.load_state_dict(sd)
+    path = tmp_path / "otcfm_cifar10_weights_step_7.pt"
+    torch.save({"net_model": sd, "ema_model": {"module." + k: v for k, v in sd.items()}, "sched": {}, "optim": {}, "step": 7}, path)
+    net = compute_fid.load_checkpoint(UNetModelWrapper(**kw), str(path)).to(DEV)
+    cfg = unet_ref.UNetConfig(16, 3, 32, 3, 1, (2,), channel_mult=(1, 2), num_heads=2)
+    x, t = randn(3, 2, 3, 16, 16), torch.tensor([0.3, 0.7])
+    y = net(t.to(DEV), x.to(DEV)).cpu()
+    torch.testing.assert_close(y, unet_ref.unet_forward(sd, cfg, x, t), rtol=2e-4, atol=5e-5)
+    # ema: target = 0.25 * target + 0.75 * source, then the forward must be that of the mixed weights
+    src = UNetModelWrapper(**kw)
+    sd2 = synth_state_dict(param_shapes(src), 1004)
+    src.load_state_dict(sd2)
+    src.to(DEV)
+    utils_cifar.ema(src, net, 0.25)
+    mixed = {k: sd[k] * 0.25 + sd2[k] * (1 - 0.25) for k in sd}
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu(), mixed[k]), k          # fused EMA kernel: bit-exact vs the eager expression
+    y2 = net(t.to(DEV), x.to(DEV)).cpu()
+    assert (y2 - y).abs().max() > 1e-3
+    torch.testing.assert_close(y2, unet_ref.unet_forward(mixed, cfg, x, t), rtol=2e-4, atol=5e-5)
+
+
+def test_ddpm_step_methods_match_the_eager_expressions():
+    """DDPM.predict_start_from_noise / q_posterior / p_mean_variance / q_sample / score_from_x0 (sde_diffusion.py:214-244) on the
+    fused per-sample kernel: bit-exact against the reference's eager expressions evaluated on the CPU (mul, mul, add)."""
+    from image_diffusion.sde_diffusion import DDPM, extract
+
+    ddpm = DDPM(50)
+    B = 6
+    x, n = randn(1, B, 3, 9, 7), randn(2, B, 3, 9, 7)     # 189 elements per sample: 4-element groups straddle samples
+    i = torch.tensor([0, 1, 17, 30, 48, 49])
+    T = {k: getattr(ddpm, k) for k in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+                                       "posterior_mean_coef2", "posterior_variance", "posterior_log_variance_clipped",
+                                       "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "recip_sqrt_m1_alphas_cumprod")}
+    e = lambda name: extract(T[name], i, x.shape)
+    xd, nd, idv = x.to(DEV), n.to(DEV), i.to(DEV)
+    got = ddpm.predict_start_from_noise(xd, idv, nd).cpu()
+    assert torch.equal(got, e("sqrt_recip_alphas_cumprod") * x - e("sqrt_recipm1_alphas_cumprod") * n)
+    mean, var, logvar, xs = ddpm.p_mean_variance(xd, nd, idv)
+    assert torch.equal(mean.cpu(), e("posterior_mean_coef1") * x + e("posterior_mean_coef2") * n)
+    assert torch.equal(var.cpu(), e("posterior_variance")) and torch.equal(logvar.cpu(), e("posterior_log_variance_clipped")) and xs is xd
+    assert torch.equal(ddpm.score_from_x0(xd, idv).cpu(), -e("recip_sqrt_m1_alphas_cumprod") * x)
+    torch.manual_seed(3)
+    xi, z = ddpm.q_sample(xd, idv)
+    torch.manual_seed(3)
+    z2 = torch.randn_like(xd)
+    assert torch.equal(z, z2)
+    assert torch.equal(xi.cpu(), e("sqrt_alphas_cumprod") * x + e("sqrt_one_minus_alphas_cumprod") * z.cpu())
