@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py - sampled images/sec of the MI355X-native CFM sampler (BASELINE.json metric).
+"""bench.py - sampled images/sec of the MI355X-native sampler (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one synthetic batch: 50-step Euler CFM sampling of 256
-CIFAR-10-shaped images (BASELINE.json configs[1]: cifar10/compute_fid.py --integration_method euler
---integration_steps 50, U-Net of cifar10/train_cifar10.py:92-101), bf16 contraction path, including the
-final uint8 quantise and (N > 1) the single RCCL all-gather of the shards.  Inputs (x0, weights) are
-resident in HBM before the timed region.  Weak scaling: every rank samples its own 256 images.
+One "step" = one pass of the hot path over one synthetic batch.  The default workload is BASELINE.json configs[1]:
+50-step Euler CFM sampling of 256 CIFAR-10-shaped images (cifar10/compute_fid.py --integration_method euler
+--integration_steps 50, U-Net of cifar10/train_cifar10.py:92-101), bf16 contraction path, including the final uint8
+quantise and (N > 1) the single RCCL all-gather of the shards.  Inputs (x0, condition, weights) are resident in HBM
+before the timed region.  Weak scaling: every rank samples its own batch.
 
-    python bench.py --gpus N --steps K --warmup W      (N > 1: launched under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--precision bf16|fp32]
+    (N > 1: launched under torch.distributed.run)
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = conv3x3_ws_kernel, measured live with
-HIP events around every one of its launches in one forward, on the launch stream) and `cpu_baseline` (the fp32
-PyTorch-CPU oracle timed on the host cores on a bounded sample; rank 0, N = 1 only).
+Other workloads (--workload; the parity tests of the same configurations are tests/test_gpu_configs.py):
+    cifar10_inpaint_ddpm50_b512        BASELINE cfg 3: CIFAR U-Net in=6, centred 16x16 = -2, Amortized DDPM Ns=50, device Philox
+    cifar10_inpaint_ddim50_b512        the same with the build-defined DDIM(eta=0) extension (cfg 3 names DDIM)
+    flowers64_superres_euler100_b256   BASELINE cfg 4 shard: Flowers-64 net (FiLM, up/down ResBlocks) in=6 = x || bilinear(16->64), 100 Euler
+    px128_inpaint_ddim100_b128         BASELINE cfg 5 shard: 128 px, attention at 32/16/8, in=6, free-form mask, DDIM Ns=100
+    cifar64_cfm_euler50_b256           64x64 unconditional (north_star: "32x32 and 64x64 batches"): CIFAR net widened to 64 px
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, measured live with HIP events around every one of its
+launches in one forward, on the launch stream; plus the whole-path MFMA / HBM fractions) and `cpu_baseline` (the fp32
+PyTorch-CPU oracle timed on the host cores on a bounded sample; rank 0, N = 1, default workload only).
 """
 import argparse
 import json
@@ -31,11 +39,35 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP1
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
+CIFAR = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+             channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
+FLOWERS = dict(image_size=64, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(4,),
+               channel_mult=(1, 2, 3, 4), num_heads=4, num_head_channels=64, use_scale_shift_norm=True, resblock_updown=True)
+PX128 = dict(image_size=128, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(4, 8, 16),
+             channel_mult=(1, 1, 2, 3, 4), num_heads=4, num_head_channels=64)
+
 WORKLOADS = {
-    # name: (model kwargs for torchcfm-style wrapper, batch per GPU, Euler steps)
-    "cifar10_cfm_euler50_b256": dict(dim=(3, 32, 32), num_res_blocks=2, num_channels=128, channel_mult=[1, 2, 2, 2], num_heads=4,
-                                     num_head_channels=64, attention_resolutions="16", dropout=0.1),
+    # name: net = UNetModel kwargs, kind = cfm | ddpm | ddim, batch per GPU, nfe, cond = None | center | superres | freeform
+    "cifar10_cfm_euler50_b256": dict(net=CIFAR, kind="cfm", batch=256, nfe=50, cond=None,
+                                     metric="sampled images/sec (50-step, 32x32)",
+                                     unet="mc128 mult(1,2,2,2) 2 resblocks attn@16x16 heads4x64 (35.7M params)"),
+    "cifar10_inpaint_ddpm50_b512": dict(net=dict(CIFAR, in_channels=6), kind="ddpm", batch=512, nfe=50, cond="center",
+                                        metric="sampled images/sec (50-step Amortized DDPM, 32x32 centre-mask in-painting)",
+                                        unet="CIFAR arch, in_channels 6 (x || condition)"),
+    "cifar10_inpaint_ddim50_b512": dict(net=dict(CIFAR, in_channels=6), kind="ddim", batch=512, nfe=50, cond="center",
+                                        metric="sampled images/sec (50-step DDIM, 32x32 centre-mask in-painting)",
+                                        unet="CIFAR arch, in_channels 6 (x || condition)"),
+    "flowers64_superres_euler100_b256": dict(net=FLOWERS, kind="cfm", batch=256, nfe=100, cond="superres",
+                                             metric="sampled images/sec (100-step Euler, 64x64 4x super-resolution)",
+                                             unet="Flowers-64: mc128 mult(1,2,3,4) FiLM up/down ResBlocks attn@16x16, in 6 (68.2M params)"),
+    "px128_inpaint_ddim100_b128": dict(net=PX128, kind="ddim", batch=128, nfe=100, cond="freeform",
+                                       metric="sampled images/sec (100-step DDIM, 128x128 free-form in-painting)",
+                                       unet="128 px: mc128 mult(1,1,2,3,4) attn@32/16/8 heads x64, in 6 (74.6M params)"),
+    "cifar64_cfm_euler50_b256": dict(net=dict(CIFAR, image_size=64, attention_resolutions=(4,)), kind="cfm", batch=256, nfe=50, cond=None,
+                                     metric="sampled images/sec (50-step, 64x64)",
+                                     unet="CIFAR arch at 64x64 (attention at 16x16)"),
 }
+DEFAULT = "cifar10_cfm_euler50_b256"
 
 
 def cpu_baseline(sd, steps_sample=10, batch=64, nfe=50):
@@ -58,19 +90,45 @@ def cpu_baseline(sd, steps_sample=10, batch=64, nfe=50):
                       f"extrapolated to {nfe} steps; torch.set_num_threads({cores})"}
 
 
+def make_condition(kind, B, C, S, dev, seed):
+    """Synthetic condition tensors of SURVEY 8(d): U(-1,1) images with the masked pixels set to the -2 sentinel, or a U(-1,1)
+    low-res image bilinearly upsampled (built once, outside the timed region: the reference builds them once per batch too)."""
+    if kind is None:
+        return None
+    g = torch.Generator(device="cpu").manual_seed(1000 + seed)
+    if kind == "superres":
+        import torch.nn.functional as F
+
+        low = torch.rand(B, C, S // 4, S // 4, generator=g) * 2 - 1
+        return F.interpolate(low, (S, S), mode="bilinear").to(dev).contiguous()
+    cond = torch.rand(B, C, S, S, generator=g) * 2 - 1
+    if kind == "center":
+        cond[:, :, S // 4: 3 * S // 4, S // 4: 3 * S // 4] = -2.0
+    elif kind == "freeform":
+        from mi355.synth import free_form_mask
+
+        m = free_form_mask(2000 + seed, min(B, 16), S, S, 0.4)
+        m = m.repeat((B + m.shape[0] - 1) // m.shape[0], 1, 1, 1)[:B]
+        cond = torch.where(m.expand_as(cond), torch.full_like(cond, -2.0), cond)
+    return cond.to(dev).contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
-    ap.add_argument("--nfe", type=int, default=50, help="Euler steps per sample")
+    ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
+    ap.add_argument("--nfe", type=int, default=0, help="network evaluations per sample (default: the workload's)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-out", default="", help="write the per-op HIP-event profile of one forward to this JSON file")
     a = ap.parse_args()
 
+    from mi355 import _lib
     from mi355 import dist as mdist
+    from mi355.ops import default_ops
     from mi355.synth import synth_state_dict
 
     rank, world, local = mdist.init_from_env()
@@ -80,23 +138,34 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from image_diffusion.unet import param_shapes
-    from torchcfm_compat import UNetModelWrapper
+    from image_diffusion.sde_diffusion import DDPM
+    from image_diffusion.unet import UNetModel, param_shapes
 
-    name = "cifar10_cfm_euler50_b256"
-    net = UNetModelWrapper(precision=a.precision, **WORKLOADS[name])
+    name = a.workload
+    wl = WORKLOADS[name]
+    net = UNetModel(precision=a.precision, **wl["net"])
     sd = synth_state_dict(param_shapes(net), 1234)  # no trained checkpoint exists offline: seeded, de-zeroed weights
     net.load_state_dict(sd)
     net.to(dev)
     eng = net.engine(dev)
-    B, nfe = a.batch, a.nfe
-    t_span = torch.linspace(0, 1, nfe + 1).tolist()
+    B, nfe = a.batch or wl["batch"], a.nfe or wl["nfe"]
+    S, Cx = wl["net"]["image_size"], wl["net"]["out_channels"]
     g = torch.Generator(device=dev).manual_seed(rank)
-    x0 = torch.randn(B, 3, 32, 32, device=dev, generator=g)
+    x0 = torch.randn(B, Cx, S, S, device=dev, generator=g)
+    cond = make_condition(wl["cond"], B, Cx, S, dev, rank)
+    t_span = torch.linspace(0, 1, nfe + 1).tolist()
+    tables = DDPM(nfe).host_tables() if wl["kind"] != "cfm" else None
+    step_no = [0]
 
     def one_step():
         x = x0.clone()
-        _, _, u8 = eng.cfm_euler(x, t_span, want_u8=True)
+        if wl["kind"] == "cfm":
+            _, _, u8 = eng.cfm_euler(x, t_span, cond=cond, want_u8=True)
+        else:
+            step_no[0] += 1
+            mode = _lib.DDPM_AMORTIZED if wl["kind"] == "ddpm" else _lib.DDIM
+            eng.ddpm_sample(x, tables, mode=mode, cond=cond, seed=(rank << 32) + step_no[0])   # device Philox noise
+            u8 = default_ops.quantize_u8(x)
         return mdist.all_gather_batch(u8, B * world) if world > 1 else u8
 
     for _ in range(a.warmup):
@@ -116,11 +185,11 @@ def main():
     assert out.shape[0] == B * world and out.dtype == torch.uint8
 
     # ---- roofline of the dominant kernel, HIP events around every launch of one forward (on the launch stream) ----
-    # Dominant kernel (rocprofv3 --kernel-trace: ~43 % of GPU time, profiles/): conv3x3_ws_kernel, the warp-specialised persistent
-    # 3x3 implicit-GEMM; mi355_unet_profile reports its launches as tile_m == 256.  Algorithmic FLOPs = 2 * MACs of the conv.
+    # Dominant kernel (rocprofv3 --kernel-trace, profiles/): conv3x3_ws_kernel, the warp-specialised persistent 3x3 implicit-GEMM;
+    # mi355_unet_profile reports its launches as tile_m == 256.  Algorithmic FLOPs = 2 * MACs of the conv.
     tt = torch.full((B,), 0.5, device=dev)
-    eng.profile(x0, tt)  # warm
-    recs = eng.profile(x0, tt)
+    eng.profile(x0, tt, cond)  # warm
+    recs = eng.profile(x0, tt, cond)
     conv = [r for r in recs if r["kind"] == "conv"]
     dom = [r for r in conv if r["tile"][0] == 256] or conv
     by = {}
@@ -133,12 +202,20 @@ def main():
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
     achieved = dfl / (dms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(REPO, "profiles", "r1_pmc_hbm_traffic.json")   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
-    if os.path.exists(pmc_file) and a.precision == "bf16" and B == 256:
-        pj = json.load(open(pmc_file))
-        ent = pj.get("kernels", {}).get("conv3x3_ws_kernel")
-        if ent:
-            traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r1_pmc_hbm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
+    for pmc_name in ("r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
+        pmc_file = os.path.join(REPO, "profiles", pmc_name)
+        if os.path.exists(pmc_file) and a.precision == "bf16" and name == DEFAULT and B == 256:
+            ent = json.load(open(pmc_file)).get("kernels", {}).get("conv3x3_ws_kernel")
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{pmc_name} (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
+                break
+    # whole path: algorithmic FLOPs / bytes of one network evaluation (SURVEY 8d accounting: the engine's plan counts 2*MAC of every
+    # contraction and in + out activation bytes of every contraction op, weights once) over the measured time per evaluation
+    st = eng.stats(B)
+    per_eval_s = dt / (a.steps * nfe)
+    flops_eval = st["conv_flops"] + st["attn_flops"]
+    bytes_eval = st["act_bytes"] + st["weight_bytes"]
     roofline = {
         "kernel": "conv3x3_ws_kernel<%s> (warp-specialised persistent 3x3 implicit-GEMM; %d of %d conv launches per forward)" % (a.precision, len(dom), len(conv)),
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -149,21 +226,28 @@ def main():
         "share_of_forward": round(dms / fwd_ms, 3),
         "all_conv_kernels": {"launches": len(conv), "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2), "share_of_forward": round(cms / fwd_ms, 3)},
         "forward_ms_by_kind": {k: round(v["ms"], 3) for k, v in by.items()},
+        "whole_path": {
+            "ms_per_network_evaluation": round(1e3 * per_eval_s, 4), "launches_per_evaluation": st["launches"],
+            "algorithmic_tflop_per_evaluation": round(flops_eval / 1e12, 4), "algorithmic_gb_per_evaluation": round(bytes_eval / 1e9, 4),
+            "achieved_mfma": round(flops_eval / per_eval_s / 1e12, 1), "achieved_mfma_frac": round(flops_eval / per_eval_s / 1e12 / peak, 4),
+            "achieved_hbm": round(bytes_eval / per_eval_s / 1e9, 1), "achieved_hbm_frac": round(bytes_eval / per_eval_s / 1e9 / PEAK_HBM_GBS, 4),
+            "note": "time per evaluation = timed region / (steps * nfe): includes the step-update / quantise kernels and (N>1) the all-gather",
+        },
     }
     if a.profile_out and rank == 0:
         os.makedirs(os.path.dirname(os.path.abspath(a.profile_out)), exist_ok=True)
-        json.dump({"batch": B, "precision": a.precision, "ops": recs}, open(a.profile_out, "w"), indent=1)
+        json.dump({"workload": name, "batch": B, "precision": a.precision, "ops": recs}, open(a.profile_out, "w"), indent=1)
 
     res = {
-        "metric": "sampled images/sec (50-step, 32x32)", "value": round(B * world * a.steps / dt, 2), "unit": "images/s",
+        "metric": wl["metric"], "value": round(B * world * a.steps / dt, 2), "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-        "config": {"workload": name, "images_per_gpu_per_step": B, "euler_steps": nfe, "image": "3x32x32",
-                   "unet": "mc128 mult(1,2,2,2) 2 resblocks attn@16x16 heads4x64 (35.7M params)", "parallelism": f"dp{world} batch-sharded",
+        "config": {"workload": name, "images_per_gpu_per_step": B, "network_evaluations_per_sample": nfe, "sampler": wl["kind"],
+                   "image": f"{Cx}x{S}x{S}", "condition": wl["cond"], "unet": wl["unet"], "parallelism": f"dp{world} batch-sharded",
                    "weights": "synthetic seeded (no checkpoint offline)"},
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and name == DEFAULT:
         res["cpu_baseline"] = cpu_baseline(sd)
     if rank == 0:
         print(json.dumps(res))

@@ -118,3 +118,43 @@ int mi355_allow_big_lds(K kern, const char* what) {
   done.fetch_or(bit, std::memory_order_release);
   return 0;
 }
+
+// ---- fused GroupNorm statistics: per-wave partial sums from a conv epilogue -------------------------------------------------
+// The reference normalises in a separate pass (GroupNorm32, AD/image_diffusion/nn.py:11-13,87-94); here the conv that PRODUCES a
+// tensor also leaves, per (image, slot, channel quad), the fp32 sum and sum of squares of its final output values
+// (`stats[N][slots][C/4][2]`), and the consumer's statistics pass shrinks to summing those partials (gn_finalize_kernel).  A slot
+// is one wave's share of an image's pixels; every (image, slot, quad) is written by exactly one wave (plain stores: no atomics, no
+// zero-fill, and the sums are bitwise reproducible).  Epilogue layout of every conv kernel here: a lane holds, per 16x16 MFMA
+// tile (mi, ni), the 4 consecutive channels 16 ni + 4 lq .. + 3 of pixel lr = one channel quad.
+template <int NI>
+struct GnPartial {
+  float s[NI], q[NI];
+  __device__ __forceinline__ GnPartial() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { s[i] = 0.f; q[i] = 0.f; }
+  }
+  __device__ __forceinline__ void add(int ni, float v0, float v1, float v2, float v3, float valid) {
+    s[ni] += valid * ((v0 + v1) + (v2 + v3));
+    q[ni] += valid * ((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3));
+  }
+  // all-reduce over the 16 lanes of a DPP row (lr), four v_add_f32 with a DPP operand each: row_mirror, row_half_mirror,
+  // quad_perm [2,3,0,1], quad_perm [1,0,3,2]
+  static __device__ __forceinline__ float row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    return v;
+  }
+  // dst = &stats[((n * slots + slot) * (C / 4) + quad0) * 2], quad0 = channel quad of (ni = 0, lq = 0); lane (lq, lr = ni) stores
+  // the pair of quad quad0 + 4 ni + lq: one store instruction per wave, 16 lanes x 8 bytes
+  __device__ __forceinline__ void store(float* dst, int lq, int lr) {
+    float ms = 0.f, mq = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const float ts = row_sum(s[ni]), tq = row_sum(q[ni]);
+      if (lr == ni) { ms = ts; mq = tq; }
+    }
+    if (lr < NI) *reinterpret_cast<f32x2*>(dst + (size_t)(lr * 4 + lq) * 2) = f32x2{ms, mq};
+  }
+};

@@ -20,6 +20,7 @@ struct K1Args {
   const float* emb; int emb_stride;
   const void* res;
   void* out;
+  float* gn_stats; int gn_slots;     // fused GroupNorm partial sums of the output (common.h GnPartial), or null
   int lvw, lth, G, tiles_x, tiles_y, ntn;
   uint32_t bytes0, bytes1, wbytes, obytes;
 };
@@ -201,6 +202,8 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
     }
     // ---- epilogue of this output-channel tile: 16-byte stores (bf16: tile pairs via permlane16_swap) ----
     {
+      GnPartial<NI> gp;
+      const bool do_gn = p.gn_stats != nullptr;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         f32x4 ad[NI];
@@ -218,6 +221,7 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
           for (int ni = 0; ni < NI; ++ni) {
             f32x4 o = f32x4{acc[mi][ni][0] + ad[ni][0], acc[mi][ni][1] + ad[ni][1], acc[mi][ni][2] + ad[ni][2], acc[mi][ni][3] + ad[ni][3]};
             if (p.res) { const f32x4 t = __builtin_bit_cast(f32x4, rr[mi][ni]); o = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]}; }
+            if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], ovalid[mi] ? 1.f : 0.f);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, obase + ni * 16 * ESZ, 0, 0);
           }
         } else {
@@ -235,10 +239,18 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
               }
             }
             bf16x4 ta, tb;
+            float va[4], vb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              ta[j] = (bf16)(acc[mi][2 * k][j] + ad[2 * k][j] + ra[j]);
-              tb[j] = (bf16)(acc[mi][2 * k + 1][j] + ad[2 * k + 1][j] + rb[j]);
+              va[j] = acc[mi][2 * k][j] + ad[2 * k][j] + ra[j];
+              vb[j] = acc[mi][2 * k + 1][j] + ad[2 * k + 1][j] + rb[j];
+              ta[j] = (bf16)va[j];
+              tb[j] = (bf16)vb[j];
+            }
+            if (do_gn) {
+              const float vm = ovalid[mi] ? 1.f : 0.f;
+              gp.add(2 * k, va[0], va[1], va[2], va[3], vm);
+              gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], vm);
             }
             const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
             const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
@@ -247,6 +259,8 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
           }
         }
       }
+      if (do_gn)   // slot = (pixel tile of the image, pixel half wm); G == 1 (launcher), so n0 is the image
+        gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * 2 + wm) * (size_t)(p.Cout >> 2) + (co_t >> 2)) * 2, lq, lr);
     }
   }
 }
@@ -262,7 +276,7 @@ int launch1(const K1Args& a, dim3 grid, size_t lds, hipStream_t s) {
 }  // namespace
 
 // Returns 1 if this conv is not eligible (caller falls back to the generic implicit-GEMM kernel), 0 on launch, <0 on error.
-int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream) {
+int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   if (d.ks != 1 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC) return 1;
   if (d.Cout % 128 != 0 || (d.res && d.res_mode != RES_SAME)) return 1;
   const int CH = d.dtype == 0 ? 16 : 32, esz = d.dtype == 0 ? 4 : 2;
@@ -288,6 +302,7 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream) {
   a.emb = d.emb; a.emb_stride = d.emb_stride;
   a.res = d.res_mode == RES_NONE ? nullptr : d.res;
   a.out = d.out;
+  a.gn_stats = nullptr; a.gn_slots = 0;
   const int lw = ilog2_ceil(d.Ws);
   a.lvw = (1 << lw) > BM ? ilog2_ceil(BM) : lw;
   const int VW = 1 << a.lvw, thfull = BM / VW;
@@ -297,6 +312,7 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream) {
   a.tiles_y = (d.Hs + (1 << a.lth) - 1) >> a.lth;
   const int groups = (d.N + a.G - 1) / a.G;
   const int mt = groups * a.tiles_x * a.tiles_y;
+  if (d.gn_stats && a.G == 1 && 2 * a.tiles_x * a.tiles_y <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = 2 * a.tiles_x * a.tiles_y; }
   const int ntiles = d.Cout / 128;
   // all output-channel tiles in one workgroup unless that leaves CUs idle
   int ntn = ntiles;
@@ -324,5 +340,6 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream) {
   }
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
+  if (gn_slots_used) *gn_slots_used = a.gn_slots;
   return 0;
 }

@@ -37,6 +37,7 @@ struct ConvKArgs {
   const float* emb; int emb_stride;
   const void* res; int res_mode; int Hr, Wr;
   void* out; int out_mode;
+  float* gn_stats; int gn_slots;     // fused GroupNorm partial sums of the output (common.h GnPartial), or null
   int lvw, lth, G, PW, PH, NP, tiles_x, tiles_y;
   uint32_t bytes0, bytes1, wbytes, obytes, rbytes;   // buffer sizes (raw buffer descriptors: out-of-range loads return 0, stores drop)
   unsigned long long* dbg;           // diagnostic build only (-DCONV_STAMPS): per-phase cycle sums
@@ -435,6 +436,8 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
         for (int k = 0; k < NP2; ++k)
           rr[mi][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, rvo[mi] + k * PSTEP * ESZ, 0, 0));
     }
+    GnPartial<NI> gp;
+    const bool do_gn = !MULTI && p.gn_stats != nullptr;
     f32x4 add4[MULTI ? MI : 1][NI];   // bias + emb per (image, channel quad), original (unswapped) layout
 #pragma unroll
     for (int k = 0; k < (MULTI ? MI : 1); ++k)
@@ -463,6 +466,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
             const f32x4 t = __builtin_bit_cast(f32x4, rr[mi][ni]);
             o = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]};
           }
+          if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], pvalid[mi] ? 1.f : 0.f);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo[mi] + ni * 16 * ESZ, 0, 0);
         }
       } else {
@@ -481,10 +485,18 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
           }
           const f32x4 ada = add4[MULTI ? mi : 0][2 * k], adb = add4[MULTI ? mi : 0][2 * k + 1];
           bf16x4 ta, tb;
+          float va[4], vb[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            ta[j] = (bf16)(acc[mi][2 * k][j] + ada[j] + ra[j]);
-            tb[j] = (bf16)(acc[mi][2 * k + 1][j] + adb[j] + rb[j]);
+            va[j] = acc[mi][2 * k][j] + ada[j] + ra[j];
+            vb[j] = acc[mi][2 * k + 1][j] + adb[j] + rb[j];
+            ta[j] = (bf16)va[j];
+            tb[j] = (bf16)vb[j];
+          }
+          if (do_gn) {
+            const float vm = pvalid[mi] ? 1.f : 0.f;
+            gp.add(2 * k, va[0], va[1], va[2], va[3], vm);
+            gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], vm);
           }
           const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
           const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
@@ -493,6 +505,8 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
         }
       }
     }
+    if (do_gn)
+      gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * WM + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * WTN) >> 2)) * 2, lq, lr);
   } else {  // OUT_NCHW_F32 (network output): lanes lr are 16 consecutive pixels of a row -> 64-byte fp32 segments
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -668,9 +682,10 @@ ConvGeom conv_geometry(const ConvDesc& d) {
   return r;
 }
 
-int conv_launch(const ConvDesc& d, hipStream_t stream) {
+int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
+  if (gn_slots_used) *gn_slots_used = 0;
   {
-    const int r = conv1x1_try_launch(d, stream);
+    const int r = conv1x1_try_launch(d, stream, gn_slots_used);
     if (r <= 0) return r;
   }
   const int CH = chunk_of(d.dtype);
@@ -706,17 +721,27 @@ int conv_launch(const ConvDesc& d, hipStream_t stream) {
   a.emb = d.emb; a.emb_stride = d.emb_stride;
   a.res = d.res; a.res_mode = d.res ? d.res_mode : RES_NONE;
   a.out = d.out; a.out_mode = d.out_mode;
+  a.gn_stats = nullptr; a.gn_slots = 0;
   a.lvw = g.lvw; a.lth = g.lth; a.G = g.G; a.PW = g.PW; a.PH = g.PH; a.NP = g.NP;
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
   dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
+  const bool gn_ok = d.gn_stats && d.out_mode == OUT_NHWC && g.G == 1 && d.Cout % g.BN == 0 && d.Cout % 4 == 0;
   {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
+    const int ws_slots = 2 * ((g.Wo + ws::VW - 1) / ws::VW) * ((g.Ho + ws::TH - 1) / ws::TH);   // (16x16 pixel tile, 8-row half) per image
+    if (gn_ok && ws_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = ws_slots; }
     const int r = d.dtype == 0 ? launch_ws<float>(a, g.BM, g.BN, d.ks, stream) : launch_ws<bf16>(a, g.BM, g.BN, d.ks, stream);
-    if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
+    if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); if (gn_slots_used) *gn_slots_used = a.gn_slots; return 0; }
     if (r < 0) return r;
+    a.gn_stats = nullptr; a.gn_slots = 0;
+  }
+  {
+    const int slots = g.tiles_x * g.tiles_y * (g.BN == 32 ? 4 : 2);   // (pixel tile, pixel-wave) per image
+    if (gn_ok && slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = slots; }
   }
   int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream)
                         : launch_cfg<bf16>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream);
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
+  if (gn_slots_used) *gn_slots_used = a.gn_slots;
   return 0;
 }

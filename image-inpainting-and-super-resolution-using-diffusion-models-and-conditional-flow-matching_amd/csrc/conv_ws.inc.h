@@ -438,13 +438,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       // ---- epilogue: MFMA rows are channels and columns are pixels, so lane (lr, lq) holds 4 consecutive channels of
       // pixel lr per 16x16 tile; bf16 pairs of channel tiles are merged into 16-byte stores by two v_permlane16_swap ----
       const int co_s = PAIR ? nt * BN + wn * 64 + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;
+      GnPartial<NI> gp;
+      const bool do_gn = p.gn_stats != nullptr;
       auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
         uint32_t ovo[4], rvo[4];
+        float vm[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int y = y0 + wm * 8 + h * 4 + j, x = x0 + lr;
           const bool ok = y < p.Ho && x < p.Wo && co_s < p.Cout;
+          vm[j] = (y < p.Ho && x < p.Wo) ? 1.f : 0.f;
           const uint32_t opix = (uint32_t)((n0 * p.Ho + y) * p.Wo + x);
           ovo[j] = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.obytes;
           uint32_t rpix = opix;
@@ -470,6 +474,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
                 const f32x4 tt = __builtin_bit_cast(f32x4, rr[j][ni]);
                 o = f32x4{o[0] + tt[0], o[1] + tt[1], o[2] + tt[2], o[3] + tt[3]};
               }
+              if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], vm[j]);
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo[j] + ni * 16 * ESZ, 0, 0);
             }
           } else {
@@ -487,10 +492,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
                 }
               }
               bf16x4 ta, tb;
+              float va[4], vb[4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                ta[q] = (bf16)(acc[mi][2 * k][q] + ra[q]);
-                tb[q] = (bf16)(acc[mi][2 * k + 1][q] + rb[q]);
+                va[q] = acc[mi][2 * k][q] + ra[q];
+                vb[q] = acc[mi][2 * k + 1][q] + rb[q];
+                ta[q] = (bf16)va[q];
+                tb[q] = (bf16)vb[q];
+              }
+              if (do_gn) {
+                gp.add(2 * k, va[0], va[1], va[2], va[3], vm[j]);
+                gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], vm[j]);
               }
               const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
               const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
@@ -502,6 +514,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       };
       epi_half(IC<0>());
       epi_half(IC<1>());
+      if (do_gn) {   // slot = (pixel tile of the image, 8-row half); quads of this wave's 64 channels
+        const int rem = mt - n0 * tpi;
+        gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * 2 + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * 64) >> 2)) * 2, lq, lr);
+      }
       STAMP(7)
       t = t_next;
     }

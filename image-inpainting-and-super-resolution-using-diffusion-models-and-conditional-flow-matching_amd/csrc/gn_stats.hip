@@ -127,6 +127,62 @@ __global__ void __launch_bounds__(GN_THREADS) gn_affine_kernel(GnKArgs p) {
   }
 }
 
+// (a, b) of one GroupNorm site from the per-wave partial sums the producing convs left in their epilogues (common.h GnPartial:
+// stats[N][slots][C/4][2] = sum, sum of squares per channel quad): no pass over the activation.  A workgroup per image; the
+// partials are summed in a fixed order (bitwise reproducible).  The input may be the channel concat of two tensors, each with
+// its own partial buffer; a group may straddle the two (e.g. 256 + 128 channels: groups of 12).
+struct GnFinArgs {
+  const float* st0; const float* st1; int slots0, slots1, C0, C1;
+  int HW, groups; float eps;
+  const float* gamma; const float* beta; const float* film; int film_stride;
+  float* a; float* b;
+};
+__global__ void __launch_bounds__(256) gn_finalize_kernel(GnFinArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  const int C = p.C0 + p.C1, Q = C >> 2, Q0 = p.C0 >> 2, Q1 = p.C1 >> 2;
+  float* qs = fsm;            // [Q] sums
+  float* qq = fsm + Q;        // [Q] sums of squares
+  float* g_mean = qq + Q;     // [groups]
+  float* g_rstd = g_mean + p.groups;
+  const int tid = threadIdx.x, n = blockIdx.x;
+  for (int q = tid; q < Q; q += 256) {
+    const bool first = q < Q0;
+    const float* base = first ? p.st0 + ((size_t)n * p.slots0 * Q0 + q) * 2 : p.st1 + ((size_t)n * p.slots1 * Q1 + (q - Q0)) * 2;
+    const int slots = first ? p.slots0 : p.slots1, stride = (first ? Q0 : Q1) * 2;
+    float s = 0.f, sq = 0.f;
+    for (int k = 0; k < slots; ++k) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(base + (size_t)k * stride);
+      s += v[0]; sq += v[1];
+    }
+    qs[q] = s; qq[q] = sq;
+  }
+  __syncthreads();
+  const int cpg = C / p.groups, qpg = cpg >> 2;
+  if (tid < p.groups) {
+    float ts = 0.f, tq = 0.f;
+    for (int j = 0; j < qpg; ++j) { ts += qs[tid * qpg + j]; tq += qq[tid * qpg + j]; }
+    const float inv = 1.0f / ((float)cpg * (float)p.HW);
+    const float mean = ts * inv;
+    const float var = fmaxf(tq * inv - mean * mean, 0.f);
+    g_mean[tid] = mean;
+    g_rstd[tid] = 1.0f / sqrtf(var + p.eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    float a = g_rstd[g] * p.gamma[c];
+    float b = p.beta[c] - g_mean[g] * a;
+    if (p.film) {
+      const float sc = 1.0f + p.film[(size_t)n * p.film_stride + c];
+      const float sh = p.film[(size_t)n * p.film_stride + C + c];
+      a *= sc;
+      b = b * sc + sh;
+    }
+    p.a[(size_t)n * C + c] = a;
+    p.b[(size_t)n * C + c] = b;
+  }
+}
+
 // Standalone GroupNorm(+SiLU) on NCHW fp32 (parity-test op; one workgroup per (n, group)).
 __global__ void __launch_bounds__(256) groupnorm_nchw_kernel(const float* x, const float* gamma, const float* beta, float* y,
                                                            int C, int HW, int groups, float eps, int silu) {
@@ -210,6 +266,19 @@ int gn_affine_launch(const GnDesc& d, hipStream_t stream) {
   const size_t lds = ((size_t)2 * ppi * C + 2 * C + 2 * d.groups) * sizeof(float);
   if (d.dtype == 0) hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(d.N), dim3(GN_THREADS), lds, stream, a);
   else hipLaunchKernelGGL(gn_affine_kernel<bf16>, dim3(d.N), dim3(GN_THREADS), lds, stream, a);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int gn_finalize_launch(const GnFinDesc& d, hipStream_t stream) {
+  const int C = d.C0 + d.C1;
+  MI355_REQUIRE(d.stats0 && d.slots0 > 0 && (d.C1 == 0 || (d.stats1 && d.slots1 > 0)), -1, "gn_finalize: missing partial statistics");
+  MI355_REQUIRE(C % d.groups == 0 && (C / d.groups) % 4 == 0 && d.C0 % 4 == 0 && d.C1 % 4 == 0, -2,
+                "gn_finalize: groups must be whole channel quads");
+  MI355_REQUIRE(d.groups <= 256, -4, "gn_finalize: too many groups");
+  GnFinArgs a{d.stats0, d.stats1, d.slots0, d.slots1, d.C0, d.C1, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b};
+  const size_t lds = ((size_t)2 * (C / 4) + 2 * d.groups) * sizeof(float);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d.N), dim3(256), lds, stream, a);
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }

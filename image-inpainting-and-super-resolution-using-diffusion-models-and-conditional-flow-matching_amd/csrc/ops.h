@@ -29,6 +29,9 @@ struct ConvDesc {
   const float* emb = nullptr; int emb_stride = 0;   // per-(n, co) additive term (ResBlock emb_layers)
   const void* res = nullptr; int res_mode = RES_NONE;  // residual NHWC tensor with Cout channels
   void* out = nullptr; int out_mode = OUT_NHWC;
+  // optional fused GroupNorm statistics of the OUTPUT (common.h GnPartial): [N][slots][Cout/4][2] fp32, room for gn_slots_cap slots
+  // per image; conv_launch reports the slots it filled (0 = this launch cannot produce them: the caller runs the stats kernel)
+  float* gn_stats = nullptr; int gn_slots_cap = 0;
   void* dbg = nullptr;                      // diagnostic builds only (-DCONV_STAMPS): 9 x u64 phase-cycle sums
 };
 
@@ -43,9 +46,9 @@ size_t conv_packed_weight_bytes(int dtype, int Cout, int Cin, int ks);
 int conv_tile_n(int Cout);
 // host-side packing: w_host [Cout][Cin][ks][ks] fp32 (Cin = logical input channels; padded to a chunk)
 void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks, void* dst_host);
-int conv_launch(const ConvDesc& d, hipStream_t stream);
+int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
 // 1x1 GEMM with a stationary activation tile (conv1x1.hip): 0 = launched, 1 = not eligible, <0 = error
-int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream);
+int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
 
 // ---- GroupNorm statistics -> per-(n, channel) affine ----------------------------------------------
 // a[n,c] = rstd * gamma[c] (* (1 + film_scale)), b[n,c] = beta[c] - mean * rstd * gamma[c] (FiLM folded)
@@ -64,6 +67,17 @@ struct GnDesc {
   void* y = nullptr; int y_silu = 0;   // optional: also write silu?(a*x + b), NHWC [N][HW][C0 + C1] (the consumer conv then has no prologue)
 };
 int gn_affine_launch(const GnDesc& d, hipStream_t stream);
+// The same (a, b) from the partial sums the producing convs left (ConvDesc::gn_stats): no pass over the activation.
+struct GnFinDesc {
+  const float* stats0 = nullptr; int slots0 = 0, C0 = 0;
+  const float* stats1 = nullptr; int slots1 = 0, C1 = 0;
+  int N = 0, HW = 0, groups = 32;
+  float eps = 1e-5f;
+  const float* gamma = nullptr; const float* beta = nullptr;
+  const float* film = nullptr; int film_stride = 0;
+  float* a = nullptr; float* b = nullptr;
+};
+int gn_finalize_launch(const GnFinDesc& d, hipStream_t stream);
 // out = avgpool2x2(silu?(a * in + b)) on NHWC tensors (a, b per (n, c), may be null): the ResBlock(down=True) input path
 int affine_pool_launch(int dtype, const void* in, const float* a, const float* b, int silu, void* out, int N, int Hs, int Ws, int C,
                        hipStream_t s);

@@ -15,7 +15,12 @@ struct ParamInfo {
 // Parameter inventory in reference state_dict order (UNetModel.__init__, unet.py:564-706).
 int unet_enumerate_params(const mi355_unet_config& cfg, std::vector<ParamInfo>& out);
 
-struct PlanTensor { int C, H, W; bool f32; size_t offset_per_image; };  // element type T unless f32
+struct PlanTensor {
+  int C, H, W; bool f32; size_t offset_per_image;   // element type T unless f32
+  // fused GroupNorm statistics (common.h GnPartial): set when a GroupNorm site that takes its (a, b) from partial sums reads this
+  // tensor; the producing conv fills stats[N][slots][C/4][2] at stats_off_per_image * N floats into the statistics arena
+  int stats_cap = 0; size_t stats_off_per_image = 0;
+};
 
 enum OpKind { OP_GN = 0, OP_CONV = 1, OP_ATTN = 2, OP_RESAMPLE = 3, OP_POOLAFF = 4 };
 
@@ -45,6 +50,7 @@ struct mi355_unet {
   int in_pad = 0;      // first conv's padded input channels
   int max_gn_c = 0;
   size_t act_elems_per_image = 0;  // activation arena (elements of T) per image
+  size_t stats_floats_per_image = 0;   // partial GroupNorm statistics arena (fp32) per image
   int in_tensor = -1, out_channels = 0;
   // stats per image
   double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;

@@ -98,6 +98,22 @@ struct Walker {
     PlanOp op; op.kind = OP_GN; op.src0 = s0; op.src1 = s1;
     op.gamma_off = put_f32(wname, {C}); op.beta_off = put_f32(bname, {C}); op.film_emb_off = film_off;
     if (may_apply && T(s0).H * T(s0).W <= max_hw) { op.dst = tensor(C, T(s0).H, T(s0).W); op.pro_silu = apply_silu; }
+    else {
+      // larger images: take the statistics from the partial sums the producing convs leave in their epilogues when the groups are
+      // whole channel quads of each source (C multiple of 128 for GroupNorm32); decided per launch (a producer that cannot
+      // provide them, e.g. a resample pass, leaves the site on the statistics kernel)
+      static const int fuse = getenv("MI355_GN_FUSE") ? atoi(getenv("MI355_GN_FUSE")) : 1;
+      const int C1 = s1 >= 0 ? T(s1).C : 0;
+      if (fuse && (C / 32) % 4 == 0 && T(s0).C % 4 == 0 && C1 % 4 == 0) {
+        for (int s : {s0, s1}) {
+          if (s < 0 || net->tensors[s].stats_cap) continue;
+          PlanTensor& t = net->tensors[s];
+          t.stats_cap = 4 * ((t.H * t.W + 63) / 64) + 8;   // >= slots of every kernel variant: at most one slot per 32 pixels
+          t.stats_off_per_image = net->stats_floats_per_image;
+          net->stats_floats_per_image += (size_t)t.stats_cap * (t.C / 4) * 2;
+        }
+      }
+    }
     net->ops.push_back(op);
     if (C > net->max_gn_c) net->max_gn_c = C;
     return op.dst;
@@ -386,7 +402,7 @@ int unet_build(const mi355_unet_config& cfg, const float* const* params_host, in
 }
 
 namespace {
-struct WsLayout { size_t temb, emb1, emb2, embp, gna, gnb, arena, total; };
+struct WsLayout { size_t temb, emb1, emb2, embp, gna, gnb, stats, arena, total; };
 WsLayout ws_layout(const mi355_unet* net, int B) {
   const int mc = net->cfg.model_channels, esz = net->cfg.dtype == 0 ? 4 : 2;
   WsLayout l; size_t c = 0;
@@ -397,6 +413,7 @@ WsLayout ws_layout(const mi355_unet* net, int B) {
   l.embp = take((size_t)B * net->emb_total * 4);
   l.gna = take((size_t)B * net->max_gn_c * 4);
   l.gnb = take((size_t)B * net->max_gn_c * 4);
+  l.stats = take((size_t)B * net->stats_floats_per_image * 4);
   l.arena = take(net->act_elems_per_image * (size_t)B * esz);
   l.total = c;
   return l;
@@ -419,6 +436,8 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
   auto WF = [&](size_t off) { return reinterpret_cast<const float*>(W + off); };
   auto TP = [&](int id) -> void* { return id < 0 ? nullptr : ws + l.arena + net->tensors[id].offset_per_image * (size_t)B * esz; };
+  auto SP = [&](int id) -> float* { return F(l.stats) + net->tensors[id].stats_off_per_image * (size_t)B; };
+  std::vector<int> gn_slots(net->tensors.size(), 0);   // partial-statistics slots each tensor's producer filled in THIS forward
   int rc;
   auto mark = [&](const mi355_op_profile& r) {
     if (!run.prof) return;
@@ -440,7 +459,16 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     mi355_op_profile r{};
     const PlanTensor& s0 = net->tensors[op.src0];
     const int C1 = op.src1 >= 0 ? net->tensors[op.src1].C : 0;
-    if (op.kind == OP_GN) {
+    if (op.kind == OP_GN && op.dst < 0 && gn_slots[op.src0] > 0 && (op.src1 < 0 || gn_slots[op.src1] > 0)) {
+      GnFinDesc g; g.stats0 = SP(op.src0); g.slots0 = gn_slots[op.src0]; g.C0 = s0.C;
+      if (op.src1 >= 0) { g.stats1 = SP(op.src1); g.slots1 = gn_slots[op.src1]; g.C1 = C1; }
+      g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
+      if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = estride; }
+      g.a = F(l.gna); g.b = F(l.gnb);
+      rc = gn_finalize_launch(g, stream);
+      r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
+      r.bytes = 0;   // no activation traffic: the statistics came with the producers' epilogues
+    } else if (op.kind == OP_GN) {
       GnDesc g; g.dtype = dtype; g.src0 = TP(op.src0); g.C0 = s0.C; g.src1 = TP(op.src1); g.C1 = C1;
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
       if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = estride; }
@@ -458,7 +486,10 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       if (op.res >= 0) { c.res = TP(op.res); c.res_mode = op.res_mode; }
       c.out_mode = op.out_mode;
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
-      rc = conv_launch(c, stream);
+      int slots = 0;
+      if (op.dst >= 0 && net->tensors[op.dst].stats_cap) { c.gn_stats = SP(op.dst); c.gn_slots_cap = net->tensors[op.dst].stats_cap; }
+      rc = conv_launch(c, stream, &slots);
+      if (op.dst >= 0) gn_slots[op.dst] = slots;
       if (run.prof) {
         const ConvGeom cg = conv_geometry(c);
         const int cin = s0.C + C1;

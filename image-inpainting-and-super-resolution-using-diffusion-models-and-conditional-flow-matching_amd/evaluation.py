@@ -71,3 +71,53 @@ def evaluate(cond_sample_fn, likelihood, batches, experiment_dir, num_batches=No
     with open(os.path.join(str(experiment_dir), "results.json"), "w") as f:
         json.dump(ordered, f)
     return ordered
+
+
+# ---- offline Frechet proxy -------------------------------------------------------------------------
+# The reference scores samples with cleanfid (cifar10/compute_fid.py:92-100), which downloads Inception weights and CIFAR
+# statistics - unavailable offline.  The stand-in keeps FID's formula and replaces the feature extractor by a FIXED, seeded
+# random convolutional network shipped here (three 3x3 conv + ReLU + 2x2 average-pool stages, global mean and global max pooling
+# -> 256 features).  It measures how far two SAMPLE SETS are apart in that feature space (e.g. bf16-mode vs fp32-mode samples
+# from identical x0); its scale is not comparable with a true FID, so it is always reported next to a same-distribution floor
+# (two independent sets of the same sampler).  Metric-side host code (PyTorch-CPU), not part of the sampling hot path.
+
+def random_conv_features(images_u8: torch.Tensor, seed: int = 0, chunk: int = 2048) -> torch.Tensor:
+    """uint8 [N, C, H, W] -> float64 [N, 256] features of the seeded random conv net (CPU)."""
+    import numpy as np
+    import torch.nn.functional as F
+
+    x = images_u8.detach().to("cpu")
+    C = x.shape[1]
+    rs = np.random.RandomState(seed)
+    widths = [C, 32, 64, 128]
+    ws = [torch.from_numpy((rs.standard_normal((widths[i + 1], widths[i], 3, 3)) * np.sqrt(2.0 / (9 * widths[i]))).astype(np.float32))
+          for i in range(3)]
+    feats = []
+    with torch.no_grad():
+        for s in range(0, x.shape[0], chunk):
+            h = x[s:s + chunk].float() / 127.5 - 1.0
+            for i, w in enumerate(ws):
+                h = F.relu(F.conv2d(h, w, padding=1))
+                if i < 2:
+                    h = F.avg_pool2d(h, 2)
+            feats.append(torch.cat((h.mean(dim=(2, 3)), h.amax(dim=(2, 3))), dim=1).double())
+    return torch.cat(feats, dim=0)
+
+
+def frechet_distance(f1: torch.Tensor, f2: torch.Tensor) -> float:
+    """|mu1 - mu2|^2 + Tr(S1 + S2 - 2 (S1 S2)^(1/2)) of two feature sets [N, D] (the FID formula)."""
+    import numpy as np
+
+    a, b = f1.double().numpy(), f2.double().numpy()
+    mu1, mu2 = a.mean(0), b.mean(0)
+    s1, s2 = np.cov(a, rowvar=False), np.cov(b, rowvar=False)
+    # Tr((S1 S2)^(1/2)) = sum of sqrt of the eigenvalues of S1^(1/2) S2 S1^(1/2) (symmetric PSD: numerically stable)
+    w, v = np.linalg.eigh(s1)
+    r1 = (v * np.sqrt(np.clip(w, 0, None))) @ v.T
+    ev = np.linalg.eigvalsh(r1 @ s2 @ r1)
+    tr = np.sqrt(np.clip(ev, 0, None)).sum()
+    return float(((mu1 - mu2) ** 2).sum() + np.trace(s1) + np.trace(s2) - 2.0 * tr)
+
+
+def frechet_proxy(images_a_u8: torch.Tensor, images_b_u8: torch.Tensor, seed: int = 0) -> float:
+    return frechet_distance(random_conv_features(images_a_u8, seed), random_conv_features(images_b_u8, seed))

@@ -268,3 +268,23 @@ def test_local_writer_files(tmp_path):
 
     w.write_figures(9, {"condition": Fig()})
     assert (tmp_path / "run" / "images" / "condition_9.png").exists()
+
+
+def test_frechet_proxy_properties():
+    """SURVEY 8(d)(ii) stand-in for FID: zero on identical sets, the closed form on Gaussians, grows with a distribution shift."""
+    import evaluation
+
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(4000, 5, generator=g, dtype=torch.float64) * torch.tensor([1.0, 2.0, 0.5, 1.5, 1.0]) + 0.3
+    b = torch.randn(4000, 5, generator=g, dtype=torch.float64) * torch.tensor([1.0, 2.0, 0.5, 1.5, 1.0]) + 0.3
+    assert abs(evaluation.frechet_distance(a, a)) < 1e-9
+    assert evaluation.frechet_distance(a, b) < 0.02                      # same distribution: sampling noise only
+    shifted = b + torch.tensor([1.0, 0, 0, 0, 0])
+    assert abs(evaluation.frechet_distance(a, shifted) - 1.0) < 0.1        # mean shift 1 in one axis -> |dmu|^2 = 1
+    scaled = b * 2.0                                                       # N(0.6, 4 S): Tr(S + 4S - 4S) = Tr(S) = 8.5, |dmu|^2 = 0.45
+    assert abs(evaluation.frechet_distance(a, scaled) - (8.5 + 0.45)) < 0.5
+    imgs = (torch.rand(600, 3, 32, 32, generator=g) * 255).to(torch.uint8)
+    f = evaluation.random_conv_features(imgs, seed=0)
+    assert f.shape == (600, 256) and torch.equal(f, evaluation.random_conv_features(imgs, seed=0))
+    darker = (imgs.float() * 0.8).to(torch.uint8)
+    assert evaluation.frechet_proxy(imgs[:300], imgs[300:]) < evaluation.frechet_proxy(imgs[:300], darker[300:])

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Quality delta of the measured (bf16) mode against the parity-green (fp32) mode: SURVEY.md 8(d)(ii), VERDICT r1 task 7.
+
+BASELINE configs[1] (CIFAR U-Net, 50 Euler steps), N samples (default 10 240 = 40 batches of 256) integrated from IDENTICAL x0
+in bf16 mode and in fp32 mode (fp32 mode is the one held to the CPU oracle at 2e-4: the oracle itself samples ~1 image/s and
+cannot produce 10 k).  Reports
+  * per-sample error of the final 50-step state: max-abs, RMS, and the uint8 code differences;
+  * "FID-proxy delta": Frechet distance between the two uint8 sample sets in the seeded random-conv feature space of
+    evaluation.random_conv_features, next to (a) the same-distribution floor = fp32 samples from two disjoint x0 sets and
+    (b) a scale reference = fp32 samples with 25 instead of 50 Euler steps (a real change of the sampler).
+True FID needs cleanfid's downloaded Inception weights + CIFAR statistics (cifar10/compute_fid.py:92-100): unavailable offline.
+
+    python tools/quality_delta.py [--n 10240] [--out gpurun_out/r2_quality_delta.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "image-inpainting-and-super-resolution-using-diffusion-models-and-conditional-flow-matching_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=10240)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--nfe", type=int, default=50)
+    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r2_quality_delta.json"))
+    a = ap.parse_args()
+
+    import evaluation
+    from compute_fid import build_model
+    from image_diffusion.unet import param_shapes
+    from mi355.synth import synth_state_dict
+
+    dev = torch.device("cuda:0")
+    net = build_model(128, dev, precision="bf16")
+    net.load_state_dict(synth_state_dict(param_shapes(net), 1234))
+    nb = (a.n + a.batch - 1) // a.batch
+
+    def sample_set(precision, seed0, nfe):
+        net.set_precision(precision)
+        eng = net.engine(dev)
+        ts = torch.linspace(0, 1, nfe + 1).tolist()
+        xs, u8s = [], []
+        t0 = time.perf_counter()
+        for k in range(nb):
+            g = torch.Generator(device=dev).manual_seed(seed0 + k)
+            x = torch.randn(a.batch, 3, 32, 32, device=dev, generator=g)
+            _, _, u8 = eng.cfm_euler(x, ts, want_u8=True)
+            xs.append(x.cpu()); u8s.append(u8.cpu())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{precision} nfe {nfe} seeds {seed0}..: {nb * a.batch} samples in {dt:.1f} s ({nb * a.batch / dt:.0f} img/s)", flush=True)
+        return torch.cat(xs), torch.cat(u8s)
+
+    x16, u16 = sample_set("bf16", 0, a.nfe)
+    x32, u32 = sample_set("fp32", 0, a.nfe)
+    _, u32b = sample_set("fp32", 100000, a.nfe)          # disjoint x0: same-distribution floor
+    _, u32h = sample_set("fp32", 0, a.nfe // 2)          # half the Euler steps: a real sampler change, for scale
+    err = (x16 - x32).abs()
+    per_sample_rms = (x16 - x32).pow(2).mean(dim=(1, 2, 3)).sqrt()
+    code = (u16.int() - u32.int()).abs()
+    f16, f32, f32b, f32h = (evaluation.random_conv_features(u, seed=0) for u in (u16, u32, u32b, u32h))
+    res = {
+        "workload": "cifar10_cfm_euler50 (BASELINE configs[1] net, synthetic seeded weights)", "n_samples": int(x16.shape[0]), "nfe": a.nfe,
+        "per_sample_bf16_vs_fp32": {
+            "max_abs": float(err.max()), "rms": float((x16 - x32).pow(2).mean().sqrt()), "state_abs_max": float(x32.abs().max()),
+            "worst_sample_rms": float(per_sample_rms.max()), "median_sample_rms": float(per_sample_rms.median()),
+            "uint8_mean_abs_code_diff": float(code.float().mean()), "uint8_max_code_diff": int(code.max()),
+            "uint8_fraction_equal": float((code == 0).float().mean()),
+        },
+        "frechet_proxy": {
+            "feature_space": "evaluation.random_conv_features(seed=0): 3 x (conv3x3 + ReLU [+ avgpool2]), global mean+max -> 256-d",
+            "bf16_vs_fp32_same_x0": evaluation.frechet_distance(f16, f32),
+            "floor_fp32_vs_fp32_disjoint_x0": evaluation.frechet_distance(f32, f32b),
+            "bf16_vs_fp32_disjoint_x0": evaluation.frechet_distance(f16, f32b),
+            "scale_fp32_50step_vs_25step_same_x0": evaluation.frechet_distance(f32, f32h),
+        },
+    }
+    fp = res["frechet_proxy"]
+    fp["fid_proxy_delta"] = fp["bf16_vs_fp32_disjoint_x0"] - fp["floor_fp32_vs_fp32_disjoint_x0"]
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    json.dump(res, open(a.out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
