@@ -6,10 +6,16 @@
 //
 // Layout: qkv is NHWC [N][T][3C] (the qkv 1x1 conv's output), channel order as in the reference
 // (legacy: per head [q|k|v]; new: [all q | all k | all v]).  out is NHWC [N][T][C].
-// One workgroup = 64 query rows of one (image, head); 4 waves x 16 rows.  Per 64-key tile:
-//   S^T = K Q^T   (keys on MFMA rows, queries on the lane -> column softmax is lane-local + 2 shuffles)
-//   O^T += V^T P^T (P^T is already the B operand, straight from the S^T accumulators; V is transposed
-//                   once while it is staged into LDS).
+// One workgroup = 4 waves x QB blocks of 16 query rows of one (image, head).  Per KT-key tile:
+//   S^T = K Q^T    (keys on MFMA rows, queries on the lane -> the softmax column is lane-local + 2 shuffles)
+//   O^T += V^T P^T (P^T is already the B operand, straight from the S^T accumulators)
+// K and V tiles are staged ROW-MAJOR ([key][channel], 16-byte copies, rows padded by 32 B): K is read by rows
+// (ds_read_b128), V^T comes out of the same kind of image through the hardware transpose read ds_read_b64_tr_b16
+// (bf16; 4 keys x 16 channels per 16-lane group, conflict-free with the 32-byte row pad) - no transposing stores.
+// Tiles are double-buffered (NBUF = 2): the next tile's global loads are issued right after the barrier that publishes
+// the current one and written to the other buffer after the tile's MFMAs, so there is ONE barrier per key tile and the
+// load latency hides behind the compute.  Head sizes up to 512 channels (torchcfm's default single head at 384 / 512
+// channels, mnist/train_mnist_hy.py:312-318) use 32-key tiles (and, in fp32, a single buffer) to stay inside 160 KB.
 #include "ops.h"
 
 namespace {
@@ -21,161 +27,234 @@ struct AttnKArgs {
   float scale2;
 };
 
-template <typename T, int CH>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int CH, int QB, int KT, int NBUF>
 __global__ void __launch_bounds__(256) attention_kernel(AttnKArgs p) {
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK, SZ = sizeof(T);
+  constexpr bool BF = E::DTYPE == 1;
   constexpr int KST = CH / CHUNK;           // k-steps over channels for S^T
   constexpr int CI = CH / 16;               // 16-channel row tiles of O^T
-  constexpr int KROW = CH * SZ + 32;        // K tile row stride (bytes)
-  constexpr int VROW = 64 * SZ + 16;        // V^T tile row stride (bytes), 64 keys per row
-  __shared__ __attribute__((aligned(16))) char klds[64 * KROW];
-  __shared__ __attribute__((aligned(16))) char vlds[CH * VROW];
+  constexpr int MT = KT / 16;               // 16-key row tiles of S^T per key tile
+  constexpr int ROW = CH * SZ + 32;         // K / V tile row stride (bytes)
+  constexpr int TILE = KT * ROW;            // bytes of one K (or V) tile
+  constexpr int FPR = CH / V;               // 16-B fragments per row
+  constexpr int NF = (KT * FPR + 255) / 256;   // fragments per thread per tile (K and V each)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][K tile | V tile]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB);
   const size_t rowstride = (size_t)3 * p.C;
   const T* base = reinterpret_cast<const T*>(p.qkv) + (size_t)n * p.T * rowstride;
   const int qc = h * p.qoff_h, kc = p.koff + h * p.qoff_h, vc = p.voff + h * p.qoff_h;
 
-  // Q^T fragments (B operand): lane holds Q[q0+lr][ks*CHUNK + lq*V .. +V)
-  u32x4 qf[KST];
+  // Q^T fragments (B operand): lane holds Q[q0 + 16 qb + lr][ks*CHUNK + lq*V .. +V)
+  u32x4 qf[QB][KST];
 #pragma unroll
-  for (int ks = 0; ks < KST; ++ks) {
-    qf[ks] = u32x4{0u, 0u, 0u, 0u};
-    if (q0 + lr < p.T) qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)(q0 + lr) * rowstride + qc + ks * CHUNK + lq * V);
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      const int q = q0 + 16 * qb + lr;
+      qf[qb][ks] = u32x4{0u, 0u, 0u, 0u};
+      if (q < p.T) qf[qb][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)q * rowstride + qc + ks * CHUNK + lq * V);
+    }
+
+  f32x4 o[QB][CI];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) o[qb][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  f32x4 o[CI];
+  // ---- staging: thread owns fragments e = tid + 256 u of a tile (row e / FPR, 16-B slot e % FPR), K and V alike ----
+  u32x4 kreg[NF], vreg[NF];
+  auto load_tile = [&](int kt) {
 #pragma unroll
-  for (int ci = 0; ci < CI; ++ci) o[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int ntiles = (p.T + 63) / 64;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
-    // ---- stage K [64][CH] and V^T [CH][64] ----
-    constexpr int FPR = CH / V;  // 16-B fragments per row
-    for (int e = tid; e < 64 * FPR; e += 256) {
-      const int s = e / FPR, f = e % FPR;
-      const int key = kt * 64 + s;
-      u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-      if (key < p.T) {
+    for (int u = 0; u < NF; ++u) {
+      const int e = tid + 256 * u, s = e / FPR, f = e - s * FPR;
+      const int key = kt * KT + s;
+      kreg[u] = u32x4{0u, 0u, 0u, 0u}; vreg[u] = u32x4{0u, 0u, 0u, 0u};
+      if (e < KT * FPR && key < p.T) {
         const T* rp = base + (size_t)key * rowstride;
-        kv = *reinterpret_cast<const u32x4*>(rp + kc + f * V);
-        vv = *reinterpret_cast<const u32x4*>(rp + vc + f * V);
+        kreg[u] = *reinterpret_cast<const u32x4*>(rp + kc + f * V);
+        vreg[u] = *reinterpret_cast<const u32x4*>(rp + vc + f * V);
       }
-      *reinterpret_cast<u32x4*>(klds + s * KROW + f * 16) = kv;
-      T tmp[V];
-      *reinterpret_cast<u32x4*>(tmp) = vv;
-#pragma unroll
-      for (int j = 0; j < V; ++j) *reinterpret_cast<T*>(vlds + (f * V + j) * VROW + s * SZ) = tmp[j];
     }
-    __syncthreads();
-
-    // ---- S^T = K Q^T : 4 row tiles of 16 keys ----
-    f32x4 sacc[4];
+  };
+  auto store_tile = [&](int buf) {
+    char* kb = smem + buf * (2 * TILE);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      sacc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NF; ++u) {
+      const int e = tid + 256 * u, s = e / FPR, f = e - s * FPR;
+      if (e < KT * FPR) {
+        *reinterpret_cast<u32x4*>(kb + s * ROW + f * 16) = kreg[u];
+        *reinterpret_cast<u32x4*>(kb + TILE + s * ROW + f * 16) = vreg[u];
+      }
+    }
+  };
+
+  const int ntiles = (p.T + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = NBUF == 2 ? (kt & 1) : 0;
+    __syncthreads();                        // tile kt is staged (and, NBUF == 2, every wave is done with tile kt - 1's buffer)
+    if (NBUF == 2 && kt + 1 < ntiles) load_tile(kt + 1);   // in flight during this tile's MFMAs
+    const char* klds = smem + buf * (2 * TILE);
+    const char* vlds = klds + TILE;
+
+    // ---- S^T = K Q^T : MT row tiles of 16 keys; a K fragment is read once and used by all QB query blocks ----
+    f32x4 sacc[QB][MT];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) sacc[qb][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int ks = 0; ks < KST; ++ks) {
-        u32x4 kf = *reinterpret_cast<const u32x4*>(klds + (mi * 16 + lr) * KROW + (ks * 4 + lq) * 16);
-        mma16(sacc[mi], kf, qf[ks], T());
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(klds + (mi * 16 + lr) * ROW + (ks * 4 + lq) * 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) mma16(sacc[qb][mi], kf, qf[qb][ks], T());
       }
-    }
     // ---- online softmax over keys (column = query = lane&15; rows spread over regs and lane>>4) ----
-    float mx = -INFINITY;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int qb = 0; qb < QB; ++qb) {
+      float mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 64 + mi * 16 + lq * 4 + r;
-        float v = sacc[mi][r] * p.scale2;
-        v = key < p.T ? v : -INFINITY;
-        sacc[mi][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
-    float psum = 0.f;
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * KT + mi * 16 + lq * 4 + r;
+          float v = sacc[qb][mi][r] * p.scale2;
+          v = key < p.T ? v : -INFINITY;
+          sacc[qb][mi][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qb], mx);
+      const float alpha = __expf(m_run[qb] - m_new);  // 0 on the first tile (m_run = -inf)
+      float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = __expf(sacc[mi][r] - m_new);
-        sacc[mi][r] = pv;
-        psum += pv;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-    for (int ci = 0; ci < CI; ++ci)
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(sacc[qb][mi][r] - m_new);
+          sacc[qb][mi][r] = pv;
+          psum += pv;
+        }
+      l_run[qb] = l_run[qb] * alpha + psum;
+      m_run[qb] = m_new;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[ci][r] *= alpha;
+      for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[qb][ci][r] *= alpha;
+    }
 
     // ---- O^T += V^T P^T ----
-    if constexpr (E::DTYPE == 1) {
+    if constexpr (BF) {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {  // 32 keys per MFMA
-        bf16x8 pb;
+      for (int s2 = 0; s2 < MT / 2; ++s2) {  // 32 keys per MFMA: keys 32 s2 + 4 lq + {0..3} and + 16
+        u32x4 pfrag[QB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pb[r] = (bf16)sacc[2 * s2][r]; pb[4 + r] = (bf16)sacc[2 * s2 + 1][r]; }
-        const u32x4 pfrag = __builtin_bit_cast(u32x4, pb);
+        for (int qb = 0; qb < QB; ++qb) {
+          bf16x8 pb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pb[r] = (bf16)sacc[qb][2 * s2][r]; pb[4 + r] = (bf16)sacc[qb][2 * s2 + 1][r]; }
+          pfrag[qb] = __builtin_bit_cast(u32x4, pb);
+        }
+        // transposed read: lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of a 4-key x 16-channel block and
+        // receives column (lane & 15) of its 4 rows = V^T[channel 16 ci + lr][4 consecutive keys]  (EXEC is all ones here)
+        const char* vrow = vlds + (32 * s2 + 4 * lq + (lr >> 2)) * ROW + 8 * (lr & 3);
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) {
-          const char* vr = vlds + (ci * 16 + lr) * VROW + (32 * s2 + 4 * lq) * SZ;
-          u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
-          u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16 * SZ);
-          mma16(o[ci], u32x4{lo[0], lo[1], hi[0], hi[1]}, pfrag, T());
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + ci * 32));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + 16 * ROW + ci * 32));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          const u32x4 vf = u32x4{l2[0], l2[1], h2[0], h2[1]};
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) mma16(o[qb][ci], vf, pfrag[qb], T());
         }
       }
     } else {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {  // 16 keys per fragment pair
-        const u32x4 pfrag = __builtin_bit_cast(u32x4, sacc[mi]);
+      for (int mi = 0; mi < MT; ++mi) {  // 16 keys per fragment pair: MFMA r of mma16 multiplies key 16 mi + 4 lq + r
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) {
-          u32x4 vf = *reinterpret_cast<const u32x4*>(vlds + (ci * 16 + lr) * VROW + (16 * mi + 4 * lq) * SZ);
-          mma16(o[ci], vf, pfrag, T());
+          const char* vp = vlds + (16 * mi + 4 * lq) * ROW + (16 * ci + lr) * 4;
+          const u32x4 vf = u32x4{*reinterpret_cast<const uint32_t*>(vp), *reinterpret_cast<const uint32_t*>(vp + ROW),
+                                 *reinterpret_cast<const uint32_t*>(vp + 2 * ROW), *reinterpret_cast<const uint32_t*>(vp + 3 * ROW)};
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) mma16(o[qb][ci], vf, __builtin_bit_cast(u32x4, sacc[qb][mi]), T());
         }
       }
     }
+    if (kt + 1 < ntiles) {
+      if (NBUF == 2) store_tile((kt + 1) & 1);   // the other buffer: last read during tile kt - 1, before this tile's barrier
+      else { __syncthreads(); load_tile(kt + 1); store_tile(0); }
+    }
   }
-  // ---- normalise and store: lane holds channels ci*16 + 4*lq + r of query q0 + lr ----
-  float l = l_run;
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
-  const float inv = 1.0f / l;
-  if (q0 + lr < p.T) {
-    T* op = reinterpret_cast<T*>(p.out) + ((size_t)n * p.T + q0 + lr) * p.C + h * CH;
+  // ---- normalise and store: lane holds channels ci*16 + 4*lq + r of query q0 + 16 qb + lr ----
 #pragma unroll
-    for (int ci = 0; ci < CI; ++ci) {
-      T* dst = op + ci * 16 + 4 * lq;
-      if constexpr (E::DTYPE == 0) {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{o[ci][0] * inv, o[ci][1] * inv, o[ci][2] * inv, o[ci][3] * inv};
-      } else {
-        bf16x4 t;
+  for (int qb = 0; qb < QB; ++qb) {
+    float l = l_run[qb];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int q = q0 + 16 * qb + lr;
+    if (q < p.T) {
+      T* op = reinterpret_cast<T*>(p.out) + ((size_t)n * p.T + q) * p.C + h * CH;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[ci][r] * inv);
-        *reinterpret_cast<bf16x4*>(dst) = t;
+      for (int ci = 0; ci < CI; ++ci) {
+        T* dst = op + ci * 16 + 4 * lq;
+        if constexpr (!BF) {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{o[qb][ci][0] * inv, o[qb][ci][1] * inv, o[qb][ci][2] * inv, o[qb][ci][3] * inv};
+        } else {
+          bf16x4 t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[qb][ci][r] * inv);
+          *reinterpret_cast<bf16x4*>(dst) = t;
+        }
       }
     }
   }
 }
 
+template <typename T, int CH, int QB, int KT, int NBUF>
+int launch_one(const AttnKArgs& a, hipStream_t s) {
+  auto kern = attention_kernel<T, CH, QB, KT, NBUF>;
+  constexpr size_t lds = (size_t)NBUF * 2 * KT * (CH * sizeof(T) + 32);
+  static_assert(lds <= 160 * 1024, "attention tile does not fit the LDS");
+  if (lds > 64 * 1024) { if (int rc = mi355_allow_big_lds(kern, "attention")) return rc; }
+  dim3 grid((a.T + 64 * QB - 1) / (64 * QB), a.N * a.heads);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  return 0;
+}
+
 template <typename T>
 int launch_attn(const AttnKArgs& a, int ch, hipStream_t s) {
-  dim3 grid((a.T + 63) / 64, a.N * a.heads);
-  if (ch == 32) hipLaunchKernelGGL((attention_kernel<T, 32>), grid, dim3(256), 0, s, a);
-  else if (ch == 64) hipLaunchKernelGGL((attention_kernel<T, 64>), grid, dim3(256), 0, s, a);
-  else if (ch == 128) hipLaunchKernelGGL((attention_kernel<T, 128>), grid, dim3(256), 0, s, a);
-  else { mi355_set_error("attention: head channels must be 32, 64 or 128"); return -4; }
-  return 0;
+  constexpr bool F32 = sizeof(T) == 4;
+  // two query blocks per wave (128 queries per workgroup: half the K/V staging per query) once the sequence is long enough
+  const bool wide = a.T >= 256;
+  switch (ch) {
+    case 32: return wide ? launch_one<T, 32, 2, 64, 2>(a, s) : launch_one<T, 32, 1, 64, 2>(a, s);
+    case 64: return wide ? launch_one<T, 64, 2, 64, 2>(a, s) : launch_one<T, 64, 1, 64, 2>(a, s);
+    case 96: return launch_one<T, 96, 1, 64, 2>(a, s);
+    case 128: return launch_one<T, 128, 1, 64, 2>(a, s);
+    case 192: return launch_one<T, 192, 1, 32, 2>(a, s);
+    case 256: return launch_one<T, 256, 1, 32, 2>(a, s);
+    case 384: return launch_one<T, 384, 1, 32, F32 ? 1 : 2>(a, s);
+    case 512: return launch_one<T, 512, 1, 32, F32 ? 1 : 2>(a, s);
+    default: break;
+  }
+  mi355_set_error("attention: head channels must be one of 32, 64, 96, 128, 192, 256, 384, 512 (got " + std::to_string(ch) + ")");
+  return -4;
 }
 
 }  // namespace

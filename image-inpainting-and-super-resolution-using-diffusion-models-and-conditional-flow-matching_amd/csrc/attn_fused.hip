@@ -1,0 +1,320 @@
+// AttentionBlock front half in ONE kernel: GroupNorm-apply -> qkv 1x1 conv -> QK^T / fp32 softmax / PV.
+//
+// Reference: AttentionBlock._forward (AD/image_diffusion/unet.py:395-401): qkv = self.qkv(self.norm(x)); h = self.attention(qkv)
+// with QKVAttentionLegacy / QKVAttention (:433-448, :464-483).  Unfused, the [B, T, 3C] qkv tensor makes a round trip through
+// memory between a 1x1-conv launch and the attention launch (100 MB at B = 256, T = 256, C = 256); here it never exists:
+// one workgroup = one (image, head), 8 waves, each wave owns T/8 tokens:
+//   phase 1  D[out channel][token] = Wqkv_h (192 x C) . GN(x)^T: the head's q, k, v rows of the packed 1x1 weights stream through
+//            LDS in 64-byte channel chunks (double-buffered, register-prefetched, one barrier per chunk); the x operand goes
+//            straight from global memory to registers (a wave's tokens are its own) with the GroupNorm affine applied in flight;
+//   phase 2  q stays in registers - an accumulator tile is the next MFMA's B operand as it stands (rows = channels = the summed
+//            index); k and v are written ROW-MAJOR into LDS (they alias the dead weight buffers), k with the channel order the
+//            q fragments have, so a K fragment is one ds_read_b128;
+//   phase 3  S^T = K Q^T, online softmax, O^T += V^T P^T over the resident K / V with no barrier at all (V^T through the
+//            hardware transpose read ds_read_b64_tr_b16, as in attention.hip).
+// Shapes: head size 64, T = 128 or 256 tokens, C <= 512 (the 16x16 / 8x16 attention levels of every mc = 128 configuration);
+// anything else runs the unfused ops.  The four heads of an image are dispatched 8 workgroups apart (same XCD under the
+// round-robin placement, speed only), so x is fetched into one L2 once.
+#include "ops.h"
+
+namespace {
+
+struct AttnFuseArgs {
+  const void* x; const float* ga; const float* gb;
+  const void* w; const float* bias;
+  void* out;
+  int N, T, C, heads, nchunks, new_order;
+  float scale2;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int QB>
+__global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
+  using E = Elem<T>;
+  constexpr int V = E::VEC, CHUNK = E::CHUNK, SZ = sizeof(T), CH = 64;
+  constexpr bool BF = E::DTYPE == 1;
+  constexpr int KST = CH / CHUNK, CI = CH / 16, NCT = 12;   // k-steps of S^T, channel tiles of O^T, 16-row tiles of the head's q|k|v rows
+  constexpr int ROW = CH * SZ + 32;                          // K / V row stride in LDS (bytes)
+  constexpr int TT = 128 * QB;                               // tokens
+  constexpr int WBUF = 192 * 64;                             // one chunk of the head's weight rows
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* klds = smem;                       // [TT][ROW]                       (phase 2 on)
+  char* vlds = smem + TT * ROW;            // [TT][ROW]
+  char* wlds = smem;                       // 2 x WBUF, aliases K             (phase 1)
+  float* ablds = reinterpret_cast<float*>(smem + 2 * WBUF);   // a[C] | b[C]  (phase 1)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  // workgroup -> (image, head): heads of one image are 8 workgroups apart
+  const int w = blockIdx.x, grp = w >> 3;
+  const int n = (w & 7) + 8 * (grp / p.heads), h = grp % p.heads;
+  if (n >= p.N) return;                    // whole workgroup (no barrier was reached)
+  const int C = p.C;
+  const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)n * TT * C;
+  const int tok0 = wave * (16 * QB);
+
+  // rows of this head in the [3C] output channels of the qkv conv: legacy = [h*192, h*192 + 192), new = q | k | v blocks of C
+  auto grow = [&](int j) { return p.new_order ? (j >> 6) * C + h * CH + (j & 63) : h * (3 * CH) + j; };
+  const char* wsrc = reinterpret_cast<const char*>(p.w);
+  // staging fragments of a weight chunk: e = tid + 512 u < 768: row e >> 2, 16-B slot e & 3 (64-byte rows copied verbatim: the
+  // packed image's XOR swizzle depends on (row >> 1) & 3 only, and every head's row base is a multiple of 8)
+  uint32_t wso[2]; int wdo[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 512 * u, j = min(e >> 2, 191), r = grow(j);
+    wso[u] = ((uint32_t)(r >> 7) * p.nchunks) * 8192u + (uint32_t)(r & 127) * 64u + (e & 3) * 16;
+    wdo[u] = j * 64 + (e & 3) * 16;
+  }
+  u32x4 wreg[2];
+  auto load_w = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) wreg[u] = *reinterpret_cast<const u32x4*>(wsrc + wso[u] + (size_t)c * 8192);
+  };
+  auto store_w = [&](int buf) {
+    *reinterpret_cast<u32x4*>(wlds + buf * WBUF + wdo[0]) = wreg[0];
+    if (tid + 512 < 768) *reinterpret_cast<u32x4*>(wlds + buf * WBUF + wdo[1]) = wreg[1];
+  };
+  for (int c = tid; c < C; c += 512) { ablds[c] = p.ga[(size_t)n * C + c]; ablds[C + c] = p.gb[(size_t)n * C + c]; }
+  load_w(0);
+  store_w(0);
+
+  // x fragments (B operand): lane holds x[tok0 + 16 qb + lr][c*CHUNK + lq*V .. +V), one chunk ahead in registers
+  u32x4 xr[QB], xn[QB];
+  auto load_x = [&](int c, u32x4 (&dst)[QB]) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) dst[qb] = *reinterpret_cast<const u32x4*>(xb + (size_t)(tok0 + 16 * qb + lr) * C + c * CHUNK + lq * V);
+  };
+  load_x(0, xr);
+
+  f32x4 acc[NCT][QB];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) acc[ct][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---------------- phase 1: q | k | v rows of this head for the wave's tokens ----------------
+  for (int c = 0; c < p.nchunks; ++c) {
+    __syncthreads();                       // chunk c's weights (and, first time, the (a, b) table) are staged
+    const bool more = c + 1 < p.nchunks;
+    if (more) { load_w(c + 1); load_x(c + 1, xn); }
+    // GroupNorm affine on the x fragments (the attention norm has no SiLU, unet.py:379,397)
+    u32x4 xf[QB];
+    {
+      float av[V], bv[V];
+#pragma unroll
+      for (int j = 0; j < V; j += 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ablds + c * CHUNK + lq * V + j);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(ablds + C + c * CHUNK + lq * V + j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { av[j + k] = a4[k]; bv[j + k] = b4[k]; }
+      }
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float f[V];
+        frag_to_float(xr[qb], f, T());
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[j] = av[j] * f[j] + bv[j];
+        xf[qb] = float_to_frag(f, T());
+      }
+    }
+    const char* wb = wlds + (c & 1) * WBUF + lr * 64 + 16 * (lq ^ ((lr >> 1) & 3));
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const u32x4 wf = *reinterpret_cast<const u32x4*>(wb + ct * 1024);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) mma16(acc[ct][qb], wf, xf[qb], T());   // D rows = output channels, cols = tokens
+    }
+    if (more) {
+      store_w((c + 1) & 1);                // the other buffer: last read during chunk c - 1, before this chunk's barrier
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) xr[qb] = xn[qb];
+    }
+  }
+  // bias of the qkv conv: lane's rows of tile ct are channels ct*16 + 4 lq .. + 3
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + grow(ct * 16 + 4 * lq));
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ct][qb][r] += b4[r];
+  }
+
+  // ---------------- phase 2: q -> B-operand fragments; k, v -> LDS ----------------
+  u32x4 qf[QB][KST];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      if constexpr (BF) {   // 32-channel k-step = tiles 2 ks and 2 ks + 1: elements 0-3 = channels 32 ks + 4 lq + r, 4-7 = + 16
+        bf16x8 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t[r] = (bf16)acc[2 * ks][qb][r]; t[4 + r] = (bf16)acc[2 * ks + 1][qb][r]; }
+        qf[qb][ks] = __builtin_bit_cast(u32x4, t);
+      } else {
+        qf[qb][ks] = __builtin_bit_cast(u32x4, acc[ks][qb]);
+      }
+    }
+  __syncthreads();                         // every wave has finished reading the weight buffers K / V are about to overwrite
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tok = tok0 + 16 * qb + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const f32x4 kv = acc[4 + ct][qb], vv = acc[8 + ct][qb];
+      if constexpr (BF) {
+        bf16x4 kt, vt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { kt[r] = (bf16)kv[r]; vt[r] = (bf16)vv[r]; }
+        // K: the 16-byte slot (ks, lq) holds tile 2 ks (first 8 bytes) and tile 2 ks + 1 (last 8) = the q fragments' channel order
+        *reinterpret_cast<bf16x4*>(klds + tok * ROW + (ct >> 1) * 64 + lq * 16 + (ct & 1) * 8) = kt;
+        *reinterpret_cast<bf16x4*>(vlds + tok * ROW + (16 * ct + 4 * lq) * 2) = vt;   // V: natural [key][channel]
+      } else {
+        *reinterpret_cast<f32x4*>(klds + tok * ROW + ct * 64 + lq * 16) = kv;
+        *reinterpret_cast<f32x4*>(vlds + tok * ROW + (16 * ct + 4 * lq) * 4) = vv;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 3: attention over the resident K / V (no barrier) ----------------
+  f32x4 o[QB][CI];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) o[qb][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int kt = 0; kt < TT / 64; ++kt) {
+    const char* kb = klds + kt * 64 * ROW;
+    const char* vb = vlds + kt * 64 * ROW;
+    f32x4 sacc[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) sacc[qb][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < KST; ++ks) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + (mi * 16 + lr) * ROW + (ks * 4 + lq) * 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) mma16(sacc[qb][mi], kf, qf[qb][ks], T());
+      }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = sacc[qb][mi][r] * p.scale2; sacc[qb][mi][r] = v; mx = fmaxf(mx, v); }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qb], mx);
+      const float alpha = __expf(m_run[qb] - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float pv = __expf(sacc[qb][mi][r] - m_new); sacc[qb][mi][r] = pv; psum += pv; }
+      l_run[qb] = l_run[qb] * alpha + psum;
+      m_run[qb] = m_new;
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[qb][ci][r] *= alpha;
+    }
+    if constexpr (BF) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4 pfrag[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          bf16x8 pb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pb[r] = (bf16)sacc[qb][2 * s2][r]; pb[4 + r] = (bf16)sacc[qb][2 * s2 + 1][r]; }
+          pfrag[qb] = __builtin_bit_cast(u32x4, pb);
+        }
+        const char* vrow = vb + (32 * s2 + 4 * lq + (lr >> 2)) * ROW + 8 * (lr & 3);
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + ci * 32));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + 16 * ROW + ci * 32));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          const u32x4 vf = u32x4{l2[0], l2[1], h2[0], h2[1]};
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) mma16(o[qb][ci], vf, pfrag[qb], T());
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+          const char* vp = vb + (16 * mi + 4 * lq) * ROW + (16 * ci + lr) * 4;
+          const u32x4 vf = u32x4{*reinterpret_cast<const uint32_t*>(vp), *reinterpret_cast<const uint32_t*>(vp + ROW),
+                                 *reinterpret_cast<const uint32_t*>(vp + 2 * ROW), *reinterpret_cast<const uint32_t*>(vp + 3 * ROW)};
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) mma16(o[qb][ci], vf, __builtin_bit_cast(u32x4, sacc[qb][mi]), T());
+        }
+    }
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float l = l_run[qb];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    T* op = reinterpret_cast<T*>(p.out) + ((size_t)n * TT + tok0 + 16 * qb + lr) * C + h * CH;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+      T* dst = op + ci * 16 + 4 * lq;
+      if constexpr (!BF) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{o[qb][ci][0] * inv, o[qb][ci][1] * inv, o[qb][ci][2] * inv, o[qb][ci][3] * inv};
+      } else {
+        bf16x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[qb][ci][r] * inv);
+        *reinterpret_cast<bf16x4*>(dst) = t;
+      }
+    }
+  }
+}
+
+template <typename T, int QB>
+int launch_fused(const AttnFuseArgs& a, hipStream_t s) {
+  auto kern = attn_fused_kernel<T, QB>;
+  constexpr size_t kv = (size_t)2 * 128 * QB * (64 * sizeof(T) + 32);
+  const size_t ph1 = (size_t)2 * 192 * 64 + (size_t)2 * a.C * 4;
+  const size_t lds = kv > ph1 ? kv : ph1;
+  if (lds > 64 * 1024) { if (int rc = mi355_allow_big_lds(kern, "attention block")) return rc; }
+  const int grid = ((a.N + 7) / 8) * 8 * a.heads;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+  return 0;
+}
+
+}  // namespace
+
+bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch) {
+  static const int enabled = getenv("MI355_ATTN_FUSE") ? atoi(getenv("MI355_ATTN_FUSE")) : 1;
+  const int CHUNK = dtype == 0 ? 16 : 32;
+  (void)CHUNK;
+  return enabled && ch == 64 && heads * ch == C && (T == 128 || T == 256) && C % 128 == 0 && C <= 512;   // 3C % 128 == 0: 128-row weight tiles
+}
+
+int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream) {
+  MI355_REQUIRE(attn_fused_eligible(d.dtype, d.T, d.C, d.heads, d.ch), -4, "attention block: shape not supported by the fused kernel");
+  MI355_REQUIRE(d.x && d.ga && d.gb && d.w && d.bias && d.out, -1, "attention block: null argument");
+  AttnFuseArgs a;
+  a.x = d.x; a.ga = d.ga; a.gb = d.gb; a.w = d.w; a.bias = d.bias; a.out = d.out;
+  a.N = d.N; a.T = d.T; a.C = d.C; a.heads = d.heads; a.nchunks = d.C / (d.dtype == 0 ? 16 : 32); a.new_order = d.new_order;
+  a.scale2 = 1.0f / sqrtf((float)d.ch);
+  int rc;
+  if (d.dtype == 0) rc = d.T == 256 ? launch_fused<float, 2>(a, stream) : launch_fused<float, 1>(a, stream);
+  else rc = d.T == 256 ? launch_fused<bf16, 2>(a, stream) : launch_fused<bf16, 1>(a, stream);
+  if (rc) return rc;
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}

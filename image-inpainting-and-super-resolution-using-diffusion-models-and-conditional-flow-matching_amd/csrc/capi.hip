@@ -100,7 +100,7 @@ int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const fl
     }
   }
   for (int i = 0; i < NCAL; ++i) (void)hipEventDestroy(cal[i]);
-  for (auto h : ev) hipEventDestroy(h);
+  for (auto h : ev) (void)hipEventDestroy(h);
   if (rc) return rc;
   if (e != hipSuccess) { mi355_set_error(hipGetErrorString(e)); return -3; }
   const int n = (int)prof.size();

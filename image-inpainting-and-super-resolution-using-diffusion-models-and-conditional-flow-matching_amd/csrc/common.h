@@ -128,14 +128,18 @@ int mi355_allow_big_lds(K kern, const char* what) {
 // tile (mi, ni), the 4 consecutive channels 16 ni + 4 lq .. + 3 of pixel lr = one channel quad.
 template <int NI>
 struct GnPartial {
-  float s[NI], q[NI];
+  f32x2 s2[NI], q2[NI];   // element pairs: the epilogue is on the consumer waves' critical path, so v_pk_add / v_pk_fma (4 per quad)
   __device__ __forceinline__ GnPartial() {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    for (int i = 0; i < NI; ++i) { s2[i] = f32x2{0.f, 0.f}; q2[i] = f32x2{0.f, 0.f}; }
   }
-  __device__ __forceinline__ void add(int ni, float v0, float v1, float v2, float v3, float valid) {
-    s[ni] += valid * ((v0 + v1) + (v2 + v3));
-    q[ni] += valid * ((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3));
+  // valid = 1 for an in-image pixel, 0 otherwise; `masked` is wave-uniform (false when the tiling covers the image exactly)
+  __device__ __forceinline__ void add(int ni, float v0, float v1, float v2, float v3, bool masked, float valid) {
+    f32x2 lo = f32x2{v0, v1}, hi = f32x2{v2, v3};
+    if (masked) { lo *= f32x2{valid, valid}; hi *= f32x2{valid, valid}; }
+    s2[ni] += lo + hi;
+    q2[ni] = lo * lo + q2[ni];
+    q2[ni] = hi * hi + q2[ni];
   }
   // all-reduce over the 16 lanes of a DPP row (lr), four v_add_f32 with a DPP operand each: row_mirror, row_half_mirror,
   // quad_perm [2,3,0,1], quad_perm [1,0,3,2]
@@ -152,7 +156,7 @@ struct GnPartial {
     float ms = 0.f, mq = 0.f;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const float ts = row_sum(s[ni]), tq = row_sum(q[ni]);
+      const float ts = row_sum(s2[ni][0] + s2[ni][1]), tq = row_sum(q2[ni][0] + q2[ni][1]);
       if (lr == ni) { ms = ts; mq = tq; }
     }
     if (lr < NI) *reinterpret_cast<f32x2*>(dst + (size_t)(lr * 4 + lq) * 2) = f32x2{ms, mq};

@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
     {
       GnPartial<NI> gp;
       const bool do_gn = p.gn_stats != nullptr;
+      const bool gn_mask = ((p.W & VWm) | (p.H & THm)) != 0;   // partial tiles exist: out-of-image pixels must not count
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         f32x4 ad[NI];
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
           for (int ni = 0; ni < NI; ++ni) {
             f32x4 o = f32x4{acc[mi][ni][0] + ad[ni][0], acc[mi][ni][1] + ad[ni][1], acc[mi][ni][2] + ad[ni][2], acc[mi][ni][3] + ad[ni][3]};
             if (p.res) { const f32x4 t = __builtin_bit_cast(f32x4, rr[mi][ni]); o = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]}; }
-            if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], ovalid[mi] ? 1.f : 0.f);
+            if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], gn_mask, ovalid[mi] ? 1.f : 0.f);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, obase + ni * 16 * ESZ, 0, 0);
           }
         } else {
@@ -249,8 +250,8 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
             }
             if (do_gn) {
               const float vm = ovalid[mi] ? 1.f : 0.f;
-              gp.add(2 * k, va[0], va[1], va[2], va[3], vm);
-              gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], vm);
+              gp.add(2 * k, va[0], va[1], va[2], va[3], gn_mask, vm);
+              gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], gn_mask, vm);
             }
             const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
             const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);

@@ -438,6 +438,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
     }
     GnPartial<NI> gp;
     const bool do_gn = !MULTI && p.gn_stats != nullptr;
+    const bool gn_mask = ((p.Wo & VWm) | (p.Ho & THm)) != 0;   // partial tiles exist: out-of-image pixels must not count
     f32x4 add4[MULTI ? MI : 1][NI];   // bias + emb per (image, channel quad), original (unswapped) layout
 #pragma unroll
     for (int k = 0; k < (MULTI ? MI : 1); ++k)
@@ -466,7 +467,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
             const f32x4 t = __builtin_bit_cast(f32x4, rr[mi][ni]);
             o = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]};
           }
-          if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], pvalid[mi] ? 1.f : 0.f);
+          if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], gn_mask, pvalid[mi] ? 1.f : 0.f);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo[mi] + ni * 16 * ESZ, 0, 0);
         }
       } else {
@@ -495,8 +496,8 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
           }
           if (do_gn) {
             const float vm = pvalid[mi] ? 1.f : 0.f;
-            gp.add(2 * k, va[0], va[1], va[2], va[3], vm);
-            gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], vm);
+            gp.add(2 * k, va[0], va[1], va[2], va[3], gn_mask, vm);
+            gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], gn_mask, vm);
           }
           const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
           const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);

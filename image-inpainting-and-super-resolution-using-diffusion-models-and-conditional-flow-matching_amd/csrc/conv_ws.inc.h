@@ -440,6 +440,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       const int co_s = PAIR ? nt * BN + wn * 64 + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;
       GnPartial<NI> gp;
       const bool do_gn = p.gn_stats != nullptr;
+      const bool gn_mask = ((p.Wo | p.Ho) & 15) != 0;   // partial 16x16 tiles exist: out-of-image pixels must not count
       auto epi_half = [&](auto hc) {
         constexpr int h = decltype(hc)::value;
         uint32_t ovo[4], rvo[4];
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
                 const f32x4 tt = __builtin_bit_cast(f32x4, rr[j][ni]);
                 o = f32x4{o[0] + tt[0], o[1] + tt[1], o[2] + tt[2], o[3] + tt[3]};
               }
-              if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], vm[j]);
+              if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], gn_mask, vm[j]);
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo[j] + ni * 16 * ESZ, 0, 0);
             }
           } else {
@@ -501,8 +502,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
                 tb[q] = (bf16)vb[q];
               }
               if (do_gn) {
-                gp.add(2 * k, va[0], va[1], va[2], va[3], vm[j]);
-                gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], vm[j]);
+                gp.add(2 * k, va[0], va[1], va[2], va[3], gn_mask, vm[j]);
+                gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], gn_mask, vm[j]);
               }
               const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
               const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);

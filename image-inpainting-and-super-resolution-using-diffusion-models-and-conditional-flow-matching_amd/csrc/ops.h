@@ -93,6 +93,17 @@ struct AttnDesc {
   int new_order = 0;
 };
 int attention_launch(const AttnDesc& d, hipStream_t stream);
+// GroupNorm-apply -> qkv 1x1 -> attention of one AttentionBlock in one kernel (attn_fused.hip): x NHWC [N][T][C], (a, b) [N][C],
+// w / bias = the qkv conv's packed weights (conv_pack_weights, ks 1, Cout 3C) / bias [3C]; out NHWC [N][T][C]
+struct AttnFusedDesc {
+  int dtype;
+  const void* x = nullptr; const float* ga = nullptr; const float* gb = nullptr;
+  const void* w = nullptr; const float* bias = nullptr;
+  void* out = nullptr;
+  int N = 0, T = 0, C = 0, heads = 0, ch = 0, new_order = 0;
+};
+bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch);
+int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream);
 
 // ---- small fp32 ops -----------------------------------------------------------------------------------
 int timestep_embedding_launch(const float* t, int B, int dim, float max_period, float* out, hipStream_t s);

@@ -22,7 +22,7 @@ struct PlanTensor {
   int stats_cap = 0; size_t stats_off_per_image = 0;
 };
 
-enum OpKind { OP_GN = 0, OP_CONV = 1, OP_ATTN = 2, OP_RESAMPLE = 3, OP_POOLAFF = 4 };
+enum OpKind { OP_GN = 0, OP_CONV = 1, OP_ATTN = 2, OP_RESAMPLE = 3, OP_POOLAFF = 4, OP_ATTN_FUSED = 5 };
 
 struct PlanOp {
   int kind;
@@ -30,6 +30,7 @@ struct PlanOp {
   int src0 = -1, src1 = -1, dst = -1;
   // GN
   size_t gamma_off = 0, beta_off = 0; int film_emb_off = -1;
+  int fin_ok = 0;   // this site's groups are whole channel quads of each source: (a, b) may come from the producers' partial sums
   // conv
   int mode = 0, ks = 3, Cout = 0; size_t w_off = 0, bias_off = 0;
   int use_pro = 0, pro_silu = 0; int emb_off = -1; int res = -1, res_mode = 0; int out_mode = 0;

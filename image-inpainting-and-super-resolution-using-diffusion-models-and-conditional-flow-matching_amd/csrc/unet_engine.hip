@@ -105,6 +105,7 @@ struct Walker {
       static const int fuse = getenv("MI355_GN_FUSE") ? atoi(getenv("MI355_GN_FUSE")) : 1;
       const int C1 = s1 >= 0 ? T(s1).C : 0;
       if (fuse && (C / 32) % 4 == 0 && T(s0).C % 4 == 0 && C1 % 4 == 0) {
+        op.fin_ok = 1;
         for (int s : {s0, s1}) {
           if (s < 0 || net->tensors[s].stats_cap) continue;
           PlanTensor& t = net->tensors[s];
@@ -179,8 +180,25 @@ struct Walker {
   int attn_block(const std::string& p, int x, int C, int heads) {
     if (heads <= 0 || C % heads != 0) { err = "attention: bad head count"; return -1; }
     const int ch = C / heads;
-    if (ch != 32 && ch != 64 && ch != 128) { err = "attention: head channels must be 32, 64 or 128 (got " + std::to_string(ch) + ")"; return -1; }
+    {
+      bool ok = false;
+      for (int v : {32, 64, 96, 128, 192, 256, 384, 512}) ok = ok || ch == v;
+      if (!ok) { err = "attention: head channels must be one of 32, 64, 96, 128, 192, 256, 384, 512 (got " + std::to_string(ch) + ")"; return -1; }
+    }
     const int yn = add_gn(x, -1, p + ".norm.weight", p + ".norm.bias", -1, 0);
+    const double Tn_ = (double)T(x).H * T(x).W;
+    if (yn < 0 && attn_fused_eligible(dtype, T(x).H * T(x).W, C, heads, ch)) {
+      // norm-apply + qkv 1x1 + attention in one kernel (attn_fused.hip): the [T, 3C] qkv tensor never exists
+      PlanOp op; op.kind = OP_ATTN_FUSED; op.src0 = x; op.heads = heads; op.ch = ch; op.Cout = 3 * C;
+      op.w_off = put_conv(p + ".qkv.weight", 3 * C, C, 1, true);
+      op.bias_off = put_f32(p + ".qkv.bias", {3 * C});
+      op.dst = tensor(C, T(x).H, T(x).W);
+      net->ops.push_back(op);
+      net->conv_flops += 2.0 * Tn_ * 3.0 * C * C;
+      net->attn_flops += 4.0 * Tn_ * Tn_ * C;
+      net->act_bytes += (2.0 * C * Tn_) * esz;   // x in, attention output out: the qkv tensor is not algorithmic traffic any more
+      return add_conv(p + ".proj_out", op.dst, -1, C, C, 1, CONV_UNIT, true, 0, 0, -1, x, RES_SAME, OUT_NHWC);
+    }
     const int qkv = yn >= 0 ? add_conv(p + ".qkv", yn, -1, C, 3 * C, 1, CONV_UNIT, true, 0, 0, -1, -1, RES_NONE, OUT_NHWC)
                             : add_conv(p + ".qkv", x, -1, C, 3 * C, 1, CONV_UNIT, true, 1, 0, -1, -1, RES_NONE, OUT_NHWC);
     PlanOp op; op.kind = OP_ATTN; op.src0 = qkv; op.heads = heads; op.ch = ch;
@@ -441,10 +459,10 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   int rc;
   auto mark = [&](const mi355_op_profile& r) {
     if (!run.prof) return;
-    hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, stream);
+    hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, stream);
     run.prof_events->push_back(e); run.prof->push_back(r);
   };
-  if (run.prof) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, stream); run.prof_events->push_back(e); }
+  if (run.prof) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, stream); run.prof_events->push_back(e); }
   // time embedding path (fp32): emb2 = silu(time_embed(timestep_embedding(t))) ; embp = all emb_layers linears
   // in the sampler loops every image shares the step time: one embedding row, broadcast with stride 0
   const int Be = run.t_uniform ? 1 : B, estride = run.t_uniform ? 0 : net->emb_total;
@@ -459,7 +477,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     mi355_op_profile r{};
     const PlanTensor& s0 = net->tensors[op.src0];
     const int C1 = op.src1 >= 0 ? net->tensors[op.src1].C : 0;
-    if (op.kind == OP_GN && op.dst < 0 && gn_slots[op.src0] > 0 && (op.src1 < 0 || gn_slots[op.src1] > 0)) {
+    if (op.kind == OP_GN && op.fin_ok && op.dst < 0 && gn_slots[op.src0] > 0 && (op.src1 < 0 || gn_slots[op.src1] > 0)) {
       GnFinDesc g; g.stats0 = SP(op.src0); g.slots0 = gn_slots[op.src0]; g.C0 = s0.C;
       if (op.src1 >= 0) { g.stats1 = SP(op.src1); g.slots1 = gn_slots[op.src1]; g.C1 = C1; }
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
@@ -504,6 +522,14 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       r.kind = MI355_OP_ATTN; r.cin = 3 * op.heads * op.ch; r.cout = op.heads * op.ch; r.h = s0.H; r.w = s0.W;
       r.flops = 4.0 * B * (double)a.T * a.T * op.heads * op.ch;
       r.bytes = 4.0 * B * a.T * op.heads * op.ch * esz;
+    } else if (op.kind == OP_ATTN_FUSED) {
+      AttnFusedDesc a; a.dtype = dtype; a.x = TP(op.src0); a.ga = F(l.gna); a.gb = F(l.gnb); a.w = W + op.w_off; a.bias = WF(op.bias_off);
+      a.out = TP(op.dst); a.N = B; a.T = s0.H * s0.W; a.C = s0.C; a.heads = op.heads; a.ch = op.ch;
+      a.new_order = net->cfg.use_new_attention_order;
+      rc = attn_fused_launch(a, stream);
+      r.kind = MI355_OP_ATTN; r.cin = s0.C; r.cout = s0.C; r.h = s0.H; r.w = s0.W; r.ks = 1;   // ks = 1 marks the fused form
+      r.flops = 2.0 * B * (double)a.T * 3.0 * s0.C * s0.C + 4.0 * B * (double)a.T * a.T * s0.C;
+      r.bytes = 2.0 * B * a.T * (double)s0.C * esz + 3.0 * s0.C * s0.C * esz;
     } else if (op.kind == OP_POOLAFF) {
       rc = affine_pool_launch(dtype, TP(op.src0), F(l.gna), F(l.gnb), op.pro_silu, TP(op.dst), B, s0.H, s0.W, s0.C, stream);
       r.kind = MI355_OP_RESAMPLE; r.cin = s0.C; r.h = s0.H; r.w = s0.W;

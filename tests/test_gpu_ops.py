@@ -109,7 +109,12 @@ def test_qkv_attention(ops, golden, dtype, tol):
     qkv = g.t("core/qkv").to(DEV)
     torch.testing.assert_close(ops.qkv_attention(qkv, 2, False, dtype).cpu(), g.t("core/legacy"), rtol=tol, atol=tol)
     torch.testing.assert_close(ops.qkv_attention(qkv, 2, True, dtype).cpu(), g.t("core/new"), rtol=tol, atol=tol)
-    for (B, heads, ch, T) in [(2, 4, 64, 256), (3, 1, 32, 784), (2, 1, 64, 49), (2, 4, 64, 16), (1, 2, 128, 100)]:
+    shapes = [(2, 4, 64, 256), (3, 1, 32, 784), (2, 1, 64, 49), (2, 4, 64, 16), (1, 2, 128, 100),
+              (2, 4, 64, 1024),                      # BASELINE cfg 5: attention at 32x32 (two query blocks per wave, 16 key tiles)
+              (1, 3, 32, 300), (2, 1, 96, 256),      # ragged length with two query blocks; torchcfm single head at 96 channels
+              (1, 1, 192, 70), (1, 1, 256, 256),     # single-head torchcfm defaults: 32-key tiles
+              (2, 1, 384, 256), (2, 1, 512, 64)]     # SuperResModelWrapper(dim=(3,64,64), 128 ch) at 16x16 / 8x8 (train_mnist_hy.py:312-318)
+    for (B, heads, ch, T) in shapes:
         q = randn(T + ch, B, 3 * heads * ch, T)
         for new in (False, True):
             ref = unet_ref.qkv_attention(q, heads, new)
