@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(256) attention_kernel(AttnKArgs p) {
   };
 
   const int ntiles = (p.T + KT - 1) / KT;
+  const float c2 = p.scale2 * 1.4426950408889634f;
   load_tile(0);
   store_tile(0);
   for (int kt = 0; kt < ntiles; ++kt) {
@@ -122,7 +123,8 @@ __global__ void __launch_bounds__(256) attention_kernel(AttnKArgs p) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) mma16(sacc[qb][mi], kf, qf[qb][ks], T());
       }
-    // ---- online softmax over keys (column = query = lane&15; rows spread over regs and lane>>4) ----
+    // ---- online softmax over keys (column = query = lane&15; rows spread over regs and lane>>4), in the log2 domain:
+    //      p = exp2(s * c2 - m2) with c2 = ch^-1/2 * log2(e) folded into one FMA per element (max, fma, exp2, add) ----
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float mx = -INFINITY;
@@ -131,21 +133,20 @@ __global__ void __launch_bounds__(256) attention_kernel(AttnKArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * KT + mi * 16 + lq * 4 + r;
-          float v = sacc[qb][mi][r] * p.scale2;
-          v = key < p.T ? v : -INFINITY;
+          const float v = key < p.T ? sacc[qb][mi][r] : -INFINITY;
           sacc[qb][mi][r] = v;
           mx = fmaxf(mx, v);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qb], mx);
-      const float alpha = __expf(m_run[qb] - m_new);  // 0 on the first tile (m_run = -inf)
+      const float m_new = fmaxf(m_run[qb], mx * c2);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);  // 0 on the first tile (m_run = -inf)
       float psum = 0.f;
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __expf(sacc[qb][mi][r] - m_new);
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][mi][r], c2, -m_new));
           sacc[qb][mi][r] = pv;
           psum += pv;
         }

@@ -4,9 +4,11 @@
 // with QKVAttentionLegacy / QKVAttention (:433-448, :464-483).  Unfused, the [B, T, 3C] qkv tensor makes a round trip through
 // memory between a 1x1-conv launch and the attention launch (100 MB at B = 256, T = 256, C = 256); here it never exists:
 // one workgroup = one (image, head), 8 waves, each wave owns T/8 tokens:
-//   phase 1  D[out channel][token] = Wqkv_h (192 x C) . GN(x)^T: the head's q, k, v rows of the packed 1x1 weights stream through
-//            LDS in 64-byte channel chunks (double-buffered, register-prefetched, one barrier per chunk); the x operand goes
-//            straight from global memory to registers (a wave's tokens are its own) with the GroupNorm affine applied in flight;
+//   phase 1  D[out channel][token] = Wqkv_h (192 x C) . GN(x)^T: ALL of the head's q, k, v weight rows (192 x C: 96 KB at C = 256) are
+//            staged once, up front, so the K loop over 64-byte channel chunks runs without a barrier or a weight wait (a
+//            chunk is only 24 MFMAs per wave: a one-chunk-ahead prefetch cannot cover an L2 round trip); the x operand goes
+//            straight from global memory to registers (a wave's tokens are its own), two chunks ahead, with the GroupNorm
+//            affine applied in flight;
 //   phase 2  q stays in registers - an accumulator tile is the next MFMA's B operand as it stands (rows = channels = the summed
 //            index); k and v are written ROW-MAJOR into LDS (they alias the dead weight buffers), k with the channel order the
 //            q fragments have, so a K fragment is one ds_read_b128;
@@ -24,10 +26,12 @@ struct AttnFuseArgs {
   const void* w; const float* bias;
   void* out;
   int N, T, C, heads, nchunks, new_order;
+  int stage_chunks;   // weight chunks resident per stage (all of them when the head's rows fit the LDS: one stage)
   float scale2;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int I> struct IC3 { static constexpr int value = I; };
 
 template <typename T, int QB>
 __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
@@ -41,8 +45,8 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* klds = smem;                       // [TT][ROW]                       (phase 2 on)
   char* vlds = smem + TT * ROW;            // [TT][ROW]
-  char* wlds = smem;                       // 2 x WBUF, aliases K             (phase 1)
-  float* ablds = reinterpret_cast<float*>(smem + 2 * WBUF);   // a[C] | b[C]  (phase 1)
+  char* wlds = smem;                       // [nchunks][192 rows][64 B], aliases K / V    (phase 1)
+  float* ablds = reinterpret_cast<float*>(smem + (size_t)p.stage_chunks * WBUF);   // a[C] | b[C]  (phase 1)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
@@ -56,9 +60,19 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
 
   // rows of this head in the [3C] output channels of the qkv conv: legacy = [h*192, h*192 + 192), new = q | k | v blocks of C
   auto grow = [&](int j) { return p.new_order ? (j >> 6) * C + h * CH + (j & 63) : h * (3 * CH) + j; };
-  const char* wsrc = reinterpret_cast<const char*>(p.w);
-  // staging fragments of a weight chunk: e = tid + 512 u < 768: row e >> 2, 16-B slot e & 3 (64-byte rows copied verbatim: the
-  // packed image's XOR swizzle depends on (row >> 1) & 3 only, and every head's row base is a multiple of 8)
+
+  // x fragments (B operand): lane holds x[tok0 + 16 qb + lr][c*CHUNK + lq*V .. +V); a ring two chunks deep
+  u32x4 xr[3][QB];
+  auto load_x = [&](int c, u32x4 (&dst)[QB]) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) dst[qb] = *reinterpret_cast<const u32x4*>(xb + (size_t)(tok0 + 16 * qb + lr) * C + c * CHUNK + lq * V);
+  };
+  load_x(0, xr[0]);
+  if (p.nchunks > 1) load_x(1, xr[1]);
+
+  // ---- the head's weights are staged stage_chunks chunks at a time: per chunk, fragment e = tid + 512 u < 768 is (row e >> 2, 16-B
+  //      slot e & 3); 64-byte rows are copied verbatim (the packed image's XOR swizzle depends on (row >> 1) & 3 only, and every
+  //      head's row base is a multiple of 8); the per-thread source / destination offsets are chunk-invariant ----
   uint32_t wso[2]; int wdo[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -66,26 +80,27 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
     wso[u] = ((uint32_t)(r >> 7) * p.nchunks) * 8192u + (uint32_t)(r & 127) * 64u + (e & 3) * 16;
     wdo[u] = j * 64 + (e & 3) * 16;
   }
-  u32x4 wreg[2];
-  auto load_w = [&](int c) {
+  const bool second = tid + 512 < 768;
+  auto stage_weights = [&](int c0, int nc) {
+    const char* wsrc = reinterpret_cast<const char*>(p.w) + (size_t)c0 * 8192;
+    for (int cl = 0; cl < nc; cl += 4) {   // four chunks in flight per thread (8 x 16 B)
+      u32x4 t[4][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) wreg[u] = *reinterpret_cast<const u32x4*>(wsrc + wso[u] + (size_t)c * 8192);
-  };
-  auto store_w = [&](int buf) {
-    *reinterpret_cast<u32x4*>(wlds + buf * WBUF + wdo[0]) = wreg[0];
-    if (tid + 512 < 768) *reinterpret_cast<u32x4*>(wlds + buf * WBUF + wdo[1]) = wreg[1];
+      for (int k = 0; k < 4; ++k) {
+        const int cc = min(cl + k, nc - 1);
+        t[k][0] = *reinterpret_cast<const u32x4*>(wsrc + wso[0] + (size_t)cc * 8192);
+        t[k][1] = *reinterpret_cast<const u32x4*>(wsrc + wso[1] + (size_t)cc * 8192);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (cl + k < nc) {
+          *reinterpret_cast<u32x4*>(wlds + (cl + k) * WBUF + wdo[0]) = t[k][0];
+          if (second) *reinterpret_cast<u32x4*>(wlds + (cl + k) * WBUF + wdo[1]) = t[k][1];
+        }
+      }
+    }
   };
   for (int c = tid; c < C; c += 512) { ablds[c] = p.ga[(size_t)n * C + c]; ablds[C + c] = p.gb[(size_t)n * C + c]; }
-  load_w(0);
-  store_w(0);
-
-  // x fragments (B operand): lane holds x[tok0 + 16 qb + lr][c*CHUNK + lq*V .. +V), one chunk ahead in registers
-  u32x4 xr[QB], xn[QB];
-  auto load_x = [&](int c, u32x4 (&dst)[QB]) {
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) dst[qb] = *reinterpret_cast<const u32x4*>(xb + (size_t)(tok0 + 16 * qb + lr) * C + c * CHUNK + lq * V);
-  };
-  load_x(0, xr);
 
   f32x4 acc[NCT][QB];
 #pragma unroll
@@ -93,11 +108,11 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) acc[ct][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---------------- phase 1: q | k | v rows of this head for the wave's tokens ----------------
-  for (int c = 0; c < p.nchunks; ++c) {
-    __syncthreads();                       // chunk c's weights (and, first time, the (a, b) table) are staged
-    const bool more = c + 1 < p.nchunks;
-    if (more) { load_w(c + 1); load_x(c + 1, xn); }
+  // ---------------- phase 1: q | k | v rows of this head for the wave's tokens (no barrier inside a stage) ----------------
+  int c0 = 0;                              // first chunk of the resident stage
+  auto chunk = [&](int c, auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
+    if (c + 2 < p.nchunks) load_x(c + 2, xr[(slot + 2) % 3]);
     // GroupNorm affine on the x fragments (the attention norm has no SiLU, unet.py:379,397)
     u32x4 xf[QB];
     {
@@ -112,23 +127,30 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         float f[V];
-        frag_to_float(xr[qb], f, T());
+        frag_to_float(xr[slot][qb], f, T());
 #pragma unroll
         for (int j = 0; j < V; ++j) f[j] = av[j] * f[j] + bv[j];
         xf[qb] = float_to_frag(f, T());
       }
     }
-    const char* wb = wlds + (c & 1) * WBUF + lr * 64 + 16 * (lq ^ ((lr >> 1) & 3));
+    const char* wb = wlds + (c - c0) * WBUF + lr * 64 + 16 * (lq ^ ((lr >> 1) & 3));
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const u32x4 wf = *reinterpret_cast<const u32x4*>(wb + ct * 1024);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) mma16(acc[ct][qb], wf, xf[qb], T());   // D rows = output channels, cols = tokens
     }
-    if (more) {
-      store_w((c + 1) & 1);                // the other buffer: last read during chunk c - 1, before this chunk's barrier
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) xr[qb] = xn[qb];
+  };
+  // stage_chunks is a multiple of 3 (or all chunks): three chunks per trip keep the ring slot a compile-time index
+  for (c0 = 0; c0 < p.nchunks; c0 += p.stage_chunks) {
+    const int nc = min(p.stage_chunks, p.nchunks - c0);
+    if (c0 > 0) __syncthreads();           // every wave is done with the previous stage's weights
+    stage_weights(c0, nc);
+    __syncthreads();                       // this stage's weights (and, first time, the (a, b) table) are staged
+    for (int c = c0; c < c0 + nc; c += 3) {
+      chunk(c, IC3<0>());
+      if (c + 1 < c0 + nc) chunk(c + 1, IC3<1>());
+      if (c + 2 < c0 + nc) chunk(c + 2, IC3<2>());
     }
   }
   // bias of the qkv conv: lane's rows of tile ct are channels ct*16 + 4 lq .. + 3
@@ -187,6 +209,7 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci) o[qb][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const float c2 = p.scale2 * 1.4426950408889634f;
   for (int kt = 0; kt < TT / 64; ++kt) {
     const char* kb = klds + kt * 64 * ROW;
     const char* vb = vlds + kt * 64 * ROW;
@@ -204,27 +227,34 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
         for (int qb = 0; qb < QB; ++qb) mma16(sacc[qb][mi], kf, qf[qb][ks], T());
       }
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {   // log2-domain online softmax: p = exp2(s * c2 - m2), c2 = ch^-1/2 * log2(e)
       float mx = -INFINITY;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = sacc[qb][mi][r] * p.scale2; sacc[qb][mi][r] = v; mx = fmaxf(mx, v); }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qb][mi][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qb], mx);
-      const float alpha = __expf(m_run[qb] - m_new);
+      // deferred rescale: the reference maximum only moves when the tile's maximum exceeds it by more than 8 (log2 domain), so
+      // p <= 2^8 and most tiles skip the O / l rescale (alpha == 1 exactly); the decision is per query column and identical in
+      // the four lanes that share it (mx is already reduced over them)
+      const float mt = mx * c2;
+      const float m_new = mt > m_run[qb] + 8.0f ? mt : m_run[qb];
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
       float psum = 0.f;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float pv = __expf(sacc[qb][mi][r] - m_new); sacc[qb][mi][r] = pv; psum += pv; }
-      l_run[qb] = l_run[qb] * alpha + psum;
+        for (int r = 0; r < 4; ++r) { const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][mi][r], c2, -m_new)); sacc[qb][mi][r] = pv; psum += pv; }
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // wave-uniform: some column's maximum moved
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[qb][ci][r] *= alpha;
+      }
+      l_run[qb] += psum;
       m_run[qb] = m_new;
-#pragma unroll
-      for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[qb][ci][r] *= alpha;
     }
     if constexpr (BF) {
 #pragma unroll
@@ -287,8 +317,9 @@ template <typename T, int QB>
 int launch_fused(const AttnFuseArgs& a, hipStream_t s) {
   auto kern = attn_fused_kernel<T, QB>;
   constexpr size_t kv = (size_t)2 * 128 * QB * (64 * sizeof(T) + 32);
-  const size_t ph1 = (size_t)2 * 192 * 64 + (size_t)2 * a.C * 4;
+  const size_t ph1 = (size_t)a.stage_chunks * 192 * 64 + (size_t)2 * a.C * 4;   // the resident weight chunks + the (a, b) table
   const size_t lds = kv > ph1 ? kv : ph1;
+  if (lds > 160 * 1024) { mi355_set_error("attention block: LDS budget exceeded"); return -4; }
   if (lds > 64 * 1024) { if (int rc = mi355_allow_big_lds(kern, "attention block")) return rc; }
   const int grid = ((a.N + 7) / 8) * 8 * a.heads;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
@@ -311,6 +342,11 @@ int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream) {
   a.x = d.x; a.ga = d.ga; a.gb = d.gb; a.w = d.w; a.bias = d.bias; a.out = d.out;
   a.N = d.N; a.T = d.T; a.C = d.C; a.heads = d.heads; a.nchunks = d.C / (d.dtype == 0 ? 16 : 32); a.new_order = d.new_order;
   a.scale2 = 1.0f / sqrtf((float)d.ch);
+  // resident weight chunks per stage: all of them if they fit beside the (a, b) table, else the largest multiple of 3 that does
+  {
+    const int fit = (int)((160 * 1024 - (size_t)8 * d.C) / (192 * 64));
+    a.stage_chunks = a.nchunks <= fit ? a.nchunks : fit / 3 * 3;
+  }
   int rc;
   if (d.dtype == 0) rc = d.T == 256 ? launch_fused<float, 2>(a, stream) : launch_fused<float, 1>(a, stream);
   else rc = d.T == 256 ? launch_fused<bf16, 2>(a, stream) : launch_fused<bf16, 1>(a, stream);
