@@ -64,6 +64,38 @@ int mi355_unet_forward(mi355_unet* net, const float* x, int x_channels, const fl
   return unet_forward(net, x, x_channels, cond, cond_channels, t, out, batch, workspace, workspace_bytes, S(stream));
 }
 
+int mi355_unet_vjp(mi355_unet* net, const float* grad_out, float* grad_x, int x_channels, int batch, void* workspace, int64_t workspace_bytes,
+                   void* stream) {
+  MI355_REQUIRE(net && workspace, -1, "unet_vjp: null argument");
+  // the sampler scratch (t, eps / v, none) sits in front of the engine workspace, exactly as in the forward entry points
+  const int64_t engine_bytes = unet_workspace_bytes(net, batch);
+  MI355_REQUIRE(workspace_bytes >= engine_bytes, -2, "unet_vjp: workspace too small");
+  return unet_backward(net, grad_out, grad_x, x_channels, batch, workspace, workspace_bytes, S(stream));
+}
+
+int mi355_unet_plan_op(const mi355_unet* net, int index, int32_t fields[16]) {
+  MI355_REQUIRE(net && fields, -1, "plan_op: null argument");
+  if (index < 0 || index >= (int)net->ops.size()) return -1;
+  const PlanOp& o = net->ops[index];
+  const int32_t v[16] = {o.kind, o.src0, o.src1, o.dst, o.mode, o.ks, o.Cout, o.use_pro, o.pro_silu, o.res, o.res_mode, o.gn_site, o.heads, o.ch,
+                         o.dst >= 0 ? net->tensors[o.dst].C : 0, o.dst >= 0 ? net->tensors[o.dst].H : 0};
+  for (int i = 0; i < 16; ++i) fields[i] = v[i];
+  return (int)net->ops.size();
+}
+
+int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, float* out, int batch, void* workspace, int64_t workspace_bytes,
+                           void* stream) {
+  MI355_REQUIRE(net && out && workspace, -1, "read_tensor: null argument");
+  MI355_REQUIRE(tensor >= 0 && tensor < (int)net->tensors.size(), -1, "read_tensor: tensor index out of range");
+  MI355_REQUIRE(!gradient || net->cfg.differentiable, -4, "read_tensor: gradients exist in differentiable plans only");
+  const WsLayout l = unet_ws_layout(net, batch);
+  MI355_REQUIRE((int64_t)l.total <= workspace_bytes, -2, "read_tensor: workspace too small");
+  const PlanTensor& t = net->tensors[tensor];
+  const int esz = net->cfg.dtype == 0 ? 4 : 2;
+  const char* p = reinterpret_cast<const char*>(workspace) + (gradient ? l.grads : l.arena) + t.offset_per_image * (size_t)batch * esz;
+  return unpack_nchw_launch(net->cfg.dtype, p, batch, t.H * t.W, t.C, out, S(stream));
+}
+
 int mi355_unet_get_stats(const mi355_unet* net, int batch, mi355_unet_stats* out) {
   if (!net || !out) { mi355_set_error("null argument"); return -1; }
   out->launches = net->launches;
@@ -253,6 +285,13 @@ int mi355_replace_mask(float* x, const float* cond, const float* z, float pad_va
   return replace_mask_launch(x, cond, z, pad_value, noisy, sa, sb, use_philox, seed, offset, n, S(stream));
 }
 int mi355_clip(float* x, float lo, float hi, int64_t n, void* stream) { return clip_launch(x, lo, hi, n, S(stream)); }
+int mi355_guidance_seed(const float* x, const float* eps, const float* cond, float c_recip, float c_recipm1, int mode, float pad_value,
+                        int64_t elems_per_sample, float* g_eps, float* g_x, int64_t n, void* stream) {
+  return guidance_seed_launch(x, eps, cond, c_recip, c_recipm1, mode, pad_value, elems_per_sample, g_eps, g_x, n, S(stream));
+}
+int mi355_guidance_update(float* x, const float* g_x, const float* vjp, float scale, int apply, float* update, int64_t n, void* stream) {
+  return guidance_update_launch(x, g_x, vjp, scale, apply, update, n, S(stream));
+}
 int mi355_ema_update(float* target, const float* source, float decay, float one_minus_decay, int64_t n, void* stream) {
   MI355_REQUIRE(target && source, -1, "ema_update: null argument");
   return ema_update_launch(target, source, decay, one_minus_decay, n, S(stream));
@@ -311,8 +350,8 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   if (pool) { d.Hs = h / 2; d.Ws = w / 2; }
   d.mode = stride == 2 ? CONV_STRIDE2 : (resample == 2 ? CONV_UP2 : CONV_UNIT);
   const ConvGeom g = conv_geometry(d);
-  const bool nhwc = cout % 4 == 0;
-  MI355_REQUIRE(nhwc || (!emb && !res), -4, "conv2d: emb / residual epilogues need an NHWC output (cout % 4 == 0)");
+  const bool nhwc = cout % 32 == 0;
+  MI355_REQUIRE(nhwc || (!emb && !res), -4, "conv2d: emb / residual epilogues need an NHWC output (cout % 32 == 0)");
   const int Hr = res_mode == RES_UP2 ? g.Ho / 2 : g.Ho, Wr = res_mode == RES_UP2 ? g.Wo / 2 : g.Wo;
   char* p = reinterpret_cast<char*>(workspace);
   char* end = p + workspace_bytes;

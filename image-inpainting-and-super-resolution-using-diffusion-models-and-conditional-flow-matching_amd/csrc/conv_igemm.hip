@@ -20,6 +20,7 @@
 // 4 waves per workgroup, v_mfma_f32_16x16x32_bf16 (or v_mfma_f32_16x16x4_f32 in the fp32 build).
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "ops.h"
 
@@ -670,6 +671,19 @@ void conv_pack_weights(int dtype, const float* w, int Cout, int Cin, int ks, voi
       }
 }
 
+// Weights of the data-gradient conv (backward w.r.t. the input) of a [Cout][Cin][ks][ks] forward filter: the transposed conv of a
+// stride-1, padding ks/2 convolution is the same convolution with input / output channels swapped and the taps flipped,
+// W'[ci][co][ky][kx] = W[co][ci][ks-1-ky][ks-1-kx]; rows ci >= Cin (channel padding of the forward input) are zero.
+size_t conv_packed_weight_bytes_dgrad(int dtype, int Cout, int Cin, int ks, int cin_pad) { (void)Cin; return conv_packed_weight_bytes(dtype, cin_pad, Cout, ks); }
+void conv_pack_weights_dgrad(int dtype, const float* w, int Cout, int Cin, int ks, int cin_pad, void* dst) {
+  const int nt = ks * ks;
+  std::vector<float> t((size_t)cin_pad * Cout * nt, 0.f);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int tap = 0; tap < nt; ++tap) t[((size_t)ci * Cout + co) * nt + (nt - 1 - tap)] = w[((size_t)co * Cin + ci) * nt + tap];
+  conv_pack_weights(dtype, t.data(), cin_pad, Cout, ks, dst);
+}
+
 ConvGeom conv_geometry(const ConvDesc& d) {
   Geo g; compute_geo(d, g);
   ConvGeom r;
@@ -694,7 +708,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   MI355_REQUIRE(d.ks == 1 || d.ks == 3, -1, "conv: kernel size must be 1 or 3");
   MI355_REQUIRE(d.C0 % CH == 0 && d.C1 % CH == 0 && Cin > 0, -2, "conv: source channels must be multiples of the 64-byte chunk");
   MI355_REQUIRE(d.mode == CONV_UNIT || d.ks == 3, -1, "conv: resampling modes need a 3x3 kernel");
-  MI355_REQUIRE(d.out_mode == OUT_NCHW_F32 || d.Cout % 4 == 0, -2, "conv: NHWC output needs Cout % 4 == 0");
+  MI355_REQUIRE(d.out_mode == OUT_NCHW_F32 || d.Cout % 32 == 0, -2, "conv: NHWC output needs Cout % 32 == 0 (a wave stores whole 32-channel tiles)");
   MI355_REQUIRE(d.mode != CONV_POOL2 && d.res_mode != RES_POOL2, -4, "conv: average pooling is a separate pass (affine_pool / resample), not a gather mode");
   Geo g; compute_geo(d, g);
   MI355_REQUIRE(g.lds <= 160 * 1024, -4, "conv: LDS budget exceeded");

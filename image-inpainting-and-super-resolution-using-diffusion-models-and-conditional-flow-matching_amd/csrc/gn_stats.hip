@@ -17,6 +17,7 @@ struct GnKArgs {
   const float* gamma; const float* beta; const float* film; int film_stride;
   float* a; float* b;
   void* y; int y_silu;   // optional: also write silu?(a*x + b) as one NHWC tensor of C0 + C1 channels (small images: see gn_affine_launch)
+  float* mean; float* rstd;   // optional [N][groups]
 };
 
 constexpr int GN_THREADS = 512;
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(GN_THREADS) gn_affine_kernel(GnKArgs p) {
     const float var = fmaxf(tq * inv - mean * mean, 0.f);
     g_mean[tid] = mean;
     g_rstd[tid] = 1.0f / sqrtf(var + p.eps);
+    if (p.mean) { p.mean[(size_t)n * p.groups + tid] = mean; p.rstd[(size_t)n * p.groups + tid] = g_rstd[tid]; }
   }
   __syncthreads();
   for (int c = tid; c < C; c += GN_THREADS) {
@@ -261,7 +263,7 @@ int gn_affine_launch(const GnDesc& d, hipStream_t stream) {
   MI355_REQUIRE(d.C0 % V == 0 && d.C1 % V == 0, -2, "groupnorm: channels must be a multiple of the 16-byte fragment");
   MI355_REQUIRE(C / V <= GN_THREADS, -4, "groupnorm: too many channels");
   MI355_REQUIRE(d.groups <= GN_THREADS, -4, "groupnorm: too many groups");
-  GnKArgs a{d.src0, d.src1, d.C0, d.C1, d.N, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b, d.y, d.y_silu};
+  GnKArgs a{d.src0, d.src1, d.C0, d.C1, d.N, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b, d.y, d.y_silu, d.mean, d.rstd};
   const int ppi = GN_THREADS / (C / V);
   const size_t lds = ((size_t)2 * ppi * C + 2 * C + 2 * d.groups) * sizeof(float);
   if (d.dtype == 0) hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(d.N), dim3(GN_THREADS), lds, stream, a);

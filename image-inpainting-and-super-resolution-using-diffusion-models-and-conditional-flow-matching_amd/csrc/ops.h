@@ -65,6 +65,7 @@ struct GnDesc {
   float* a = nullptr;
   float* b = nullptr;
   void* y = nullptr; int y_silu = 0;   // optional: also write silu?(a*x + b), NHWC [N][HW][C0 + C1] (the consumer conv then has no prologue)
+  float* mean = nullptr; float* rstd = nullptr;   // optional [N][groups]: kept for the backward pass (reconstruction guidance)
 };
 int gn_affine_launch(const GnDesc& d, hipStream_t stream);
 // The same (a, b) from the partial sums the producing convs left (ConvDesc::gn_stats): no pass over the activation.
@@ -104,6 +105,34 @@ struct AttnFusedDesc {
 };
 bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch);
 int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream);
+
+// ---- backward (data gradient only: reconstruction guidance, AD/image_diffusion/sampling.py:136-206) --------------------------------
+void conv_pack_weights_dgrad(int dtype, const float* w_host, int Cout, int Cin, int ks, int cin_pad, void* dst_host);
+size_t conv_packed_weight_bytes_dgrad(int dtype, int Cout, int Cin, int ks, int cin_pad);
+struct GnBwdDesc {
+  int dtype;
+  const void* x0 = nullptr; const void* x1 = nullptr; int C0 = 0, C1 = 0;
+  const void* du = nullptr; int du_stride = 0;
+  int N = 0, HW = 0, groups = 32, silu = 0;
+  const float* a = nullptr; const float* b = nullptr; const float* mean = nullptr; const float* rstd = nullptr;
+  void* g0 = nullptr; void* g1 = nullptr; int acc0 = 0, acc1 = 0;
+};
+int gn_silu_bwd_launch(const GnBwdDesc& d, hipStream_t stream);
+enum { GATHER_SAME = 0, GATHER_POOL = 1, GATHER_UP = 2, GATHER_STUFF = 3 };
+int grad_gather_launch(int dtype, void* dst, const void* src, int N, int Hd, int Wd, int Cd, int Hs, int Ws, int src_cstride, int src_coff,
+                       int mode, int accumulate, float scale, hipStream_t s);
+struct AttnBwdDesc {
+  int dtype;
+  const void* qkv = nullptr; const void* a = nullptr; const void* da = nullptr; void* dqkv = nullptr;
+  float* L = nullptr; float* D = nullptr;
+  int N = 0, T = 0, heads = 0, ch = 0, new_order = 0;
+};
+int attention_bwd_launch(const AttnBwdDesc& d, hipStream_t stream);
+int guidance_seed_launch(const float* x, const float* eps, const float* cond, float c_recip, float c_recipm1, int mode, float pad,
+                         int64_t per, float* g_eps, float* g_x, int64_t n, hipStream_t s);
+int guidance_update_launch(float* x, const float* g_x, const float* vjp, float scale, int apply, float* update, int64_t n, hipStream_t s);
+// out[n][c][hw] (NCHW fp32, c < count) = in[n][hw][c0 + c] (NHWC T, row stride `stride`)
+int unpack_channels_launch(int dtype, const void* in, int N, int HW, int stride, int c0, int count, float* out, hipStream_t s);
 
 // ---- small fp32 ops -----------------------------------------------------------------------------------
 int timestep_embedding_launch(const float* t, int B, int dim, float max_period, float* out, hipStream_t s);

@@ -31,6 +31,8 @@ struct PlanOp {
   // GN
   size_t gamma_off = 0, beta_off = 0; int film_emb_off = -1;
   int fin_ok = 0;   // this site's groups are whole channel quads of each source: (a, b) may come from the producers' partial sums
+  int gn_site = -1; // differentiable plans: OP_GN = its site; OP_CONV / OP_POOLAFF with a prologue = the site whose (a, b) they apply
+  size_t wT_off = 0; int cin_pad = 0;   // differentiable plans: data-gradient weights (conv_pack_weights_dgrad) and their output channels
   // conv
   int mode = 0, ks = 3, Cout = 0; size_t w_off = 0, bias_off = 0;
   int use_pro = 0, pro_silu = 0; int emb_off = -1; int res = -1, res_mode = 0; int out_mode = 0;
@@ -52,6 +54,10 @@ struct mi355_unet {
   int max_gn_c = 0;
   size_t act_elems_per_image = 0;  // activation arena (elements of T) per image
   size_t stats_floats_per_image = 0;   // partial GroupNorm statistics arena (fp32) per image
+  // differentiable plans (reconstruction guidance): per-site (a, b, mean, rstd) kept by the forward, and the backward's scratch sizes
+  std::vector<int> site_C; std::vector<size_t> site_off;   // site k: a[C] | b[C] | mean[32] | rstd[32] floats per image at site_off[k]
+  size_t site_floats_per_image = 0;
+  size_t bwd_du_elems = 0, bwd_tmp_elems = 0, bwd_z_elems = 0, bwd_ld_floats = 0;   // per image
   int in_tensor = -1, out_channels = 0;
   // stats per image
   double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;
@@ -71,5 +77,10 @@ int unet_build(const mi355_unet_config& cfg, const float* const* params_host, in
                int64_t dev_weights_bytes, hipStream_t stream, mi355_unet** out);
 int64_t unet_weight_bytes(const mi355_unet_config& cfg);
 int64_t unet_workspace_bytes(const mi355_unet* net, int batch);
+struct WsLayout { size_t temb, emb1, emb2, embp, gna, gnb, stats, sites, arena, grads, du, tmp, z, dy, ld, total; };
+WsLayout unet_ws_layout(const mi355_unet* net, int B);
+// (d out / d x)^T grad_out of the last unet_forward on this workspace (differentiable plans only; unet_backward.hip)
+int unet_backward(const mi355_unet* net, const float* grad_out, float* grad_x, int Cx, int batch, void* workspace, int64_t workspace_bytes,
+                  hipStream_t stream);
 int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int batch,
                  void* workspace, int64_t workspace_bytes, hipStream_t stream, const UnetRun& run = UnetRun());

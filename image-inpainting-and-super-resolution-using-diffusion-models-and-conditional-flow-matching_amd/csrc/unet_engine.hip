@@ -9,6 +9,7 @@
 // Parameters arrive in the reference's state_dict order and layouts and are repacked once.
 #include "unet_engine.h"
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 
@@ -30,6 +31,7 @@ struct Walker {
   struct EmbPart { std::string name; int off, width; };
   std::vector<EmbPart> emb_parts;
   int emb_total = 0;
+  int last_site = -1;   // differentiable plans: the GroupNorm site the next prologue consumer applies
 
   bool has_attn(int ds) const {
     for (int i = 0; i < cfg.n_attention_ds; ++i) if (cfg.attention_ds[i] == ds) return true;
@@ -97,7 +99,13 @@ struct Walker {
     const int C = T(s0).C + (s1 >= 0 ? T(s1).C : 0);
     PlanOp op; op.kind = OP_GN; op.src0 = s0; op.src1 = s1;
     op.gamma_off = put_f32(wname, {C}); op.beta_off = put_f32(bname, {C}); op.film_emb_off = film_off;
-    if (may_apply && T(s0).H * T(s0).W <= max_hw) { op.dst = tensor(C, T(s0).H, T(s0).W); op.pro_silu = apply_silu; }
+    if (cfg.differentiable) {
+      // the backward pass re-derives everything from (x, a, b, mean, rstd) of each site: no applied copies, no shared (a, b) buffer
+      op.gn_site = last_site = (int)net->site_C.size();
+      net->site_C.push_back(C);
+      net->site_off.push_back(net->site_floats_per_image);
+      net->site_floats_per_image += (size_t)2 * C + 64;
+    } else if (may_apply && T(s0).H * T(s0).W <= max_hw) { op.dst = tensor(C, T(s0).H, T(s0).W); op.pro_silu = apply_silu; }
     else {
       // larger images: take the statistics from the partial sums the producing convs leave in their epilogues when the groups are
       // whole channel quads of each source (C multiple of 128 for GroupNorm32); decided per launch (a producer that cannot
@@ -131,6 +139,19 @@ struct Walker {
     else if (mode == CONV_POOL2) { Ho /= 2; Wo /= 2; }
     else if (mode == CONV_STRIDE2) { Ho = (Ho - 1) / 2 + 1; Wo = (Wo - 1) / 2 + 1; }
     op.dst = out_mode == OUT_NHWC ? tensor(Cout, Ho, Wo) : -1;
+    if (cfg.differentiable) {
+      if (use_pro) op.gn_site = last_site;
+      op.cin_pad = (int)align_up(T(s0).C + (s1 >= 0 ? T(s1).C : 0), 32);   // NHWC conv outputs come in whole 32-channel tiles
+      const float* pw = P(prefix + ".weight", conv1d ? std::vector<int64_t>{Cout, Cin_logical, 1} : std::vector<int64_t>{Cout, Cin_logical, ks, ks});
+      op.wT_off = alloc(conv_packed_weight_bytes_dgrad(dtype, Cout, Cin_logical, ks, op.cin_pad));
+      if (!dry && pw) conv_pack_weights_dgrad(dtype, pw, Cout, Cin_logical, ks, op.cin_pad, blob.data() + op.wT_off);
+      // scratch of the backward pass: the data-gradient conv's output (at the conv's own input resolution, before any pooling back),
+      // the zero-stuffed output gradient of a stride-2 conv, the pooled gradient of an up-sampling conv with a prologue
+      const size_t hw_dgrad = mode == CONV_UP2 ? (size_t)Ho * Wo : (size_t)T(s0).H * T(s0).W;
+      net->bwd_du_elems = std::max(net->bwd_du_elems, hw_dgrad * op.cin_pad);
+      if (mode == CONV_STRIDE2) net->bwd_z_elems = std::max(net->bwd_z_elems, (size_t)T(s0).H * T(s0).W * Cout);
+      net->bwd_tmp_elems = std::max(net->bwd_tmp_elems, (size_t)T(s0).H * T(s0).W * op.cin_pad);
+    }
     net->ops.push_back(op);
     const double in_elems = (double)(T(s0).C + (s1 >= 0 ? T(s1).C : 0)) * T(s0).H * T(s0).W;
     net->conv_flops += 2.0 * Ho * Wo * (double)Cout * Cin_logical * ks * ks;
@@ -155,6 +176,7 @@ struct Walker {
       if (s1 >= 0) { err = "ResBlock(down) over a channel concat is not supported"; return -1; }
       PlanOp op; op.kind = OP_POOLAFF; op.src0 = s0; op.pro_silu = 1;
       op.dst = tensor(T(s0).C, T(s0).H / 2, T(s0).W / 2);
+      if (cfg.differentiable) { op.gn_site = last_site; net->bwd_tmp_elems = std::max(net->bwd_tmp_elems, (size_t)T(s0).H * T(s0).W * T(s0).C); }
       net->ops.push_back(op);
       h1 = add_conv(p + ".in_layers.2", op.dst, -1, cin, cout, 3, CONV_UNIT, false, 0, 0, film ? -1 : eoff, -1, RES_NONE, OUT_NHWC);
       res = resample(s0, CONV_POOL2);
@@ -187,7 +209,7 @@ struct Walker {
     }
     const int yn = add_gn(x, -1, p + ".norm.weight", p + ".norm.bias", -1, 0);
     const double Tn_ = (double)T(x).H * T(x).W;
-    if (yn < 0 && attn_fused_eligible(dtype, T(x).H * T(x).W, C, heads, ch)) {
+    if (yn < 0 && !cfg.differentiable && attn_fused_eligible(dtype, T(x).H * T(x).W, C, heads, ch)) {
       // norm-apply + qkv 1x1 + attention in one kernel (attn_fused.hip): the [T, 3C] qkv tensor never exists
       PlanOp op; op.kind = OP_ATTN_FUSED; op.src0 = x; op.heads = heads; op.ch = ch; op.Cout = 3 * C;
       op.w_off = put_conv(p + ".qkv.weight", 3 * C, C, 1, true);
@@ -204,6 +226,7 @@ struct Walker {
     PlanOp op; op.kind = OP_ATTN; op.src0 = qkv; op.heads = heads; op.ch = ch;
     op.dst = tensor(C, T(x).H, T(x).W);
     net->ops.push_back(op);
+    if (cfg.differentiable) net->bwd_ld_floats = std::max(net->bwd_ld_floats, (size_t)2 * heads * T(x).H * T(x).W);
     const double Tn = (double)T(x).H * T(x).W;
     net->attn_flops += 4.0 * Tn * Tn * C;
     net->act_bytes += (4.0 * C * Tn) * esz;
@@ -419,11 +442,9 @@ int unet_build(const mi355_unet_config& cfg, const float* const* params_host, in
   return 0;
 }
 
-namespace {
-struct WsLayout { size_t temb, emb1, emb2, embp, gna, gnb, stats, arena, total; };
-WsLayout ws_layout(const mi355_unet* net, int B) {
-  const int mc = net->cfg.model_channels, esz = net->cfg.dtype == 0 ? 4 : 2;
-  WsLayout l; size_t c = 0;
+WsLayout unet_ws_layout(const mi355_unet* net, int B) {
+  const int mc = net->cfg.model_channels, esz = net->cfg.dtype == 0 ? 4 : 2, CH = net->cfg.dtype == 0 ? 16 : 32;
+  WsLayout l{}; size_t c = 0;
   auto take = [&](size_t bytes) { size_t o = c; c = align_up(c + bytes, 256); return o; };
   l.temb = take((size_t)B * mc * 4);
   l.emb1 = take((size_t)B * 4 * mc * 4);
@@ -432,11 +453,21 @@ WsLayout ws_layout(const mi355_unet* net, int B) {
   l.gna = take((size_t)B * net->max_gn_c * 4);
   l.gnb = take((size_t)B * net->max_gn_c * 4);
   l.stats = take((size_t)B * net->stats_floats_per_image * 4);
+  l.sites = take((size_t)B * net->site_floats_per_image * 4);
   l.arena = take(net->act_elems_per_image * (size_t)B * esz);
+  if (net->cfg.differentiable) {   // backward scratch: one gradient per activation tensor + the temporaries sized by the plan
+    const size_t S = (size_t)net->cfg.image_size * net->cfg.image_size;
+    l.grads = take(net->act_elems_per_image * (size_t)B * esz);
+    l.du = take(net->bwd_du_elems * (size_t)B * esz);
+    l.tmp = take(net->bwd_tmp_elems * (size_t)B * esz);
+    l.z = take(net->bwd_z_elems * (size_t)B * esz);
+    l.dy = take(S * CH * (size_t)B * esz);
+    l.ld = take(net->bwd_ld_floats * (size_t)B * 4);
+  }
   l.total = c;
   return l;
 }
-}  // namespace
+static WsLayout ws_layout(const mi355_unet* net, int B) { return unet_ws_layout(net, B); }
 
 int64_t unet_workspace_bytes(const mi355_unet* net, int batch) { return (int64_t)ws_layout(net, batch).total; }
 
@@ -491,6 +522,11 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
       if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = estride; }
       g.a = F(l.gna); g.b = F(l.gnb);
+      if (op.gn_site >= 0) {   // differentiable plan: this site's own (a, b, mean, rstd)
+        float* sp = F(l.sites) + net->site_off[op.gn_site] * (size_t)B;
+        const size_t Cs = (size_t)net->site_C[op.gn_site];
+        g.a = sp; g.b = sp + (size_t)B * Cs; g.mean = sp + (size_t)2 * B * Cs; g.rstd = g.mean + (size_t)B * 32;
+      }
       if (op.dst >= 0) { g.y = TP(op.dst); g.y_silu = op.pro_silu; }
       rc = gn_affine_launch(g, stream);
       r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
@@ -499,6 +535,10 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       ConvDesc c; c.dtype = dtype; c.src0 = TP(op.src0); c.C0 = s0.C; c.src1 = TP(op.src1); c.C1 = C1;
       c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks;
       if (op.use_pro) { c.pro_a = F(l.gna); c.pro_b = F(l.gnb); c.pro_silu = op.pro_silu; }
+      if (op.use_pro && op.gn_site >= 0) {
+        float* sp = F(l.sites) + net->site_off[op.gn_site] * (size_t)B;
+        c.pro_a = sp; c.pro_b = sp + (size_t)B * net->site_C[op.gn_site];
+      }
       c.w = W + op.w_off; c.bias = WF(op.bias_off); c.Cout = op.Cout;
       if (op.emb_off >= 0) { c.emb = F(l.embp) + op.emb_off; c.emb_stride = estride; }
       if (op.res >= 0) { c.res = TP(op.res); c.res_mode = op.res_mode; }
@@ -531,7 +571,9 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       r.flops = 2.0 * B * (double)a.T * 3.0 * s0.C * s0.C + 4.0 * B * (double)a.T * a.T * s0.C;
       r.bytes = 2.0 * B * a.T * (double)s0.C * esz + 3.0 * s0.C * s0.C * esz;
     } else if (op.kind == OP_POOLAFF) {
-      rc = affine_pool_launch(dtype, TP(op.src0), F(l.gna), F(l.gnb), op.pro_silu, TP(op.dst), B, s0.H, s0.W, s0.C, stream);
+      const float* pa = F(l.gna); const float* pb = F(l.gnb);
+      if (op.gn_site >= 0) { pa = F(l.sites) + net->site_off[op.gn_site] * (size_t)B; pb = pa + (size_t)B * net->site_C[op.gn_site]; }
+      rc = affine_pool_launch(dtype, TP(op.src0), pa, pb, op.pro_silu, TP(op.dst), B, s0.H, s0.W, s0.C, stream);
       r.kind = MI355_OP_RESAMPLE; r.cin = s0.C; r.h = s0.H; r.w = s0.W;
       r.bytes = 1.25 * B * s0.H * s0.W * (double)s0.C * esz;
     } else {

@@ -13,8 +13,9 @@ Two execution paths, both entirely on the HIP backend:
     host loop that calls it once per step and applies the fused HIP step kernels (csrc/steps.hip).
 Noise: by default drawn in-kernel (Philox4x32-10, seeded from torch.initial_seed()); parity tests
 inject the draws of the reference's `torch.randn_like` call sequence with `injected_noise([...])`.
-ReconstructionGuidance needs a backward pass through the U-Net (sampling.py:154-163) and is a
-"next" row: it raises NotImplementedError here.
+ReconstructionGuidance (sampling.py:136-206) differentiates the x0 model through the U-Net: the gradient is the HIP engine's
+vector-Jacobian product (`UNetEngine.vjp`, csrc/unet_backward.hip) of a differentiable plan of the same network, so it needs an
+`eps_model` made by `make_eps_model(network, ddpm)` around a `UNetModel`.
 """
 from __future__ import annotations
 
@@ -204,9 +205,7 @@ def get_conditional_sample_fn(eps_model: Callable, ddpm: DDPM, conditioning: Con
     if isinstance(conditioning, Replacement):
         return _replacement_sample_fn(eps_model, ddpm, conditioning, likelihood)
     if isinstance(conditioning, ReconstructionGuidance):
-        raise NotImplementedError(
-            "ReconstructionGuidance needs vmap(grad) through the U-Net (sampling.py:154-163): a 'next' row (SURVEY.md 8f), "
-            "not built in this round")
+        return _reconstruction_guidance_sample_fn(eps_model, ddpm, conditioning, likelihood)
     raise NotImplementedError(f"no sampler for conditioning type {type(conditioning).__name__}")
 
 
@@ -223,6 +222,67 @@ def _amortized_sample_fn(eps_model, ddpm, conditioning: Amortized, likelihood):
                              delta=conditioning.delta, none_value=_none_value(likelihood, xT))
         return _run_generic(eps_model, ddpm, xT, amortized=True, cond_pred=condition, cond_corr=likelihood.none_like(xT),
                             n_corrector=conditioning.n_corrector, delta=conditioning.delta)
+
+    return sample
+
+
+def _reconstruction_guidance_sample_fn(eps_model, ddpm, conditioning: ReconstructionGuidance, likelihood):
+    """sampling.py:136-206.  Per step i < int(Ns * start_fraction):
+        x_grad = vmap(grad(lambda xi: likelihood.loss(x0_model(xi, i), y)))(xi)      (x0_model = clip(predict_start_from_noise(eps_model)))
+        x_update = -gamma * alpha_i * (1 - alpha_i) * x_grad;  "before": xi += x_update (the predictor then runs on the moved xi),
+        "after": the predictor runs on xi and x_update is added to its result.
+    The losses are per sample and the network has no cross-sample coupling, so vmap(grad) is ONE batched backward pass:
+    seed kernel (clip / loss / predict_start chain rule) -> UNetEngine.vjp -> update kernel."""
+    net = getattr(eps_model, "_mi355_network", None)
+    if net is None or getattr(eps_model, "_mi355_Ns", None) != ddpm.Ns or not hasattr(net, "engine"):
+        raise NotImplementedError(
+            "ReconstructionGuidance differentiates through the network: pass an eps_model built by make_eps_model(network, ddpm) around "
+            "a UNetModel (an arbitrary callable has no backward pass on the HIP backend)")
+    if conditioning.update_rule not in ("before", "after"):
+        raise ValueError(f"unknown update_rule {conditioning.update_rule!r}")
+    if hasattr(likelihood, "pad_value"):
+        mode, pad = 0, float(likelihood.pad_value)      # Painting.loss (likelihoods.py:58-66)
+    elif type(likelihood).__name__ == "HyperResolution":
+        mode, pad = 1, 0.0                              # HyperResolution.loss (likelihoods.py:138-143)
+    else:
+        raise NotImplementedError(f"no constraint gradient for likelihood {type(likelihood).__name__}")
+
+    @torch.no_grad()
+    def sample(xT, condition):
+        if not xT.is_cuda:
+            from mi355._lib import MI355BackendError
+            raise MI355BackendError("ReconstructionGuidance sampling needs device tensors (no CPU fallback)")
+        T = _tables(ddpm)
+        alphas = ddpm.alphas.detach().to("cpu", torch.float32)
+        condition = condition.to(xT.device).float().contiguous()
+        xi = xT.detach().clone().float().contiguous()
+        B = xi.shape[0]
+        deng, eng = net.engine(xi.device, differentiable=True), net.engine(xi.device)
+        noise = _Noise(xi)
+        n_guided = int(ddpm.Ns * conditioning.start_fraction)
+        for i in reversed(range(ddpm.Ns)):
+            t = torch.full((B,), 1.0 * i / ddpm.Ns, device=xi.device, dtype=torch.float32)
+            update, eps = None, None
+            if i < n_guided:
+                eps = deng.forward(xi, t)
+                g_eps, g_x = _ops.guidance_seed(xi, eps, condition, float(T["sqrt_recip_alphas_cumprod"][i]),
+                                                float(T["sqrt_recipm1_alphas_cumprod"][i]), mode, pad)
+                vjp = deng.vjp(g_eps)
+                a_i = float(alphas[i])
+                scale = float(conditioning.gamma) * a_i * (1.0 - a_i)
+                before = conditioning.update_rule == "before"
+                update = _ops.guidance_update_(xi, g_x, vjp, scale, before)
+                if before:
+                    eps = None                       # xi moved: the predictor needs the network at the new point
+            if eps is None:
+                eps = eng.forward(xi, t)
+            _predictor(eps, xi, i, T, noise)
+            if update is not None and conditioning.update_rule == "after":
+                _ops.euler_step_(xi, update, 1.0)    # pred_img += x_update
+            for _ in range(conditioning.n_corrector):
+                epc = eng.forward(xi, t)
+                _corrector(epc, xi, i, T, ddpm, conditioning.delta, noise)
+        return process_x0(xi)
 
     return sample
 

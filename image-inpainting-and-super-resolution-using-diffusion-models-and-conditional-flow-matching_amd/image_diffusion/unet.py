@@ -172,6 +172,8 @@ class UNetModel(nn.Module):
             node.register_parameter(parts[-1], p)
         self._engine: Optional[UNetEngine] = None
         self._engine_key = None
+        self._dengine: Optional[UNetEngine] = None   # differentiable plan (reconstruction guidance): built on first use
+        self._dengine_key = None
         self._weights_generation = 0
 
     # ---- engine management -------------------------------------------------------------------
@@ -179,6 +181,7 @@ class UNetModel(nn.Module):
         """'bf16' (bf16 storage + bf16 MFMA, fp32 accumulate / GN / softmax) or 'fp32' (exact f32 MFMA)."""
         self.precision = precision
         self._engine = None
+        self._dengine = None
         return self
 
     def invalidate_engine(self):
@@ -186,6 +189,7 @@ class UNetModel(nn.Module):
         kernel such as the fused EMA update): drop the packed copy so the next call re-packs the current values."""
         self._weights_generation += 1
         self._engine = None
+        self._dengine = None
         return self
 
     def _cfg_kwargs(self):
@@ -196,8 +200,9 @@ class UNetModel(nn.Module):
                     use_scale_shift_norm=self.use_scale_shift_norm, resblock_updown=self.resblock_updown,
                     use_new_attention_order=self.use_new_attention_order)
 
-    def engine(self, device=None) -> UNetEngine:
-        """The packed HIP engine for the CURRENT parameter values (re-packed when any parameter changed)."""
+    def engine(self, device=None, differentiable: bool = False) -> UNetEngine:
+        """The packed HIP engine for the CURRENT parameter values (re-packed when any parameter changed).
+        differentiable=True: the plan that keeps what `UNetEngine.vjp` needs (its own handle and weight copy)."""
         params = list(self.parameters())
         device = torch.device(device) if device is not None else params[0].device
         if device.type != "cuda":
@@ -207,6 +212,11 @@ class UNetModel(nn.Module):
             device = torch.device("cuda", torch.cuda.current_device())
         key = (str(device), self.precision, self._weights_generation, tuple(p._version for p in params),
                tuple(p.data_ptr() for p in params))
+        if differentiable:
+            if self._dengine is None or key != self._dengine_key:
+                self._dengine = UNetEngine(self._cfg_kwargs(), self.state_dict(), device, self.precision, differentiable=True)
+                self._dengine_key = key
+            return self._dengine
         if self._engine is None or key != self._engine_key:
             self._engine = UNetEngine(self._cfg_kwargs(), self.state_dict(), device, self.precision)
             self._engine_key = key
@@ -214,6 +224,7 @@ class UNetModel(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         self._engine = None
+        self._dengine = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     # ---- reference API ---------------------------------------------------------------------

@@ -29,7 +29,7 @@ class UNetConfigC(C.Structure):
         ("attention_ds", C.c_int32 * 8), ("n_channel_mult", C.c_int32), ("channel_mult", C.c_int32 * 8),
         ("conv_resample", C.c_int32), ("num_heads", C.c_int32), ("num_head_channels", C.c_int32),
         ("num_heads_upsample", C.c_int32), ("use_scale_shift_norm", C.c_int32), ("resblock_updown", C.c_int32),
-        ("use_new_attention_order", C.c_int32), ("dtype", C.c_int32),
+        ("use_new_attention_order", C.c_int32), ("dtype", C.c_int32), ("differentiable", C.c_int32),
     ]
 
 
@@ -73,6 +73,9 @@ SIGNATURES = {
     "mi355_unet_destroy": (None, [_VP]),
     "mi355_unet_workspace_bytes": (_I64, [_VP, _I]),
     "mi355_unet_forward": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
+    "mi355_unet_vjp": (_I, [_VP, _VP, _VP, _I, _I, _VP, _I64, _VP]),
+    "mi355_unet_plan_op": (_I, [_VP, _I, C.POINTER(C.c_int32)]),
+    "mi355_unet_read_tensor": (_I, [_VP, _I, _I, _VP, _I, _VP, _I64, _VP]),
     "mi355_unet_get_stats": (_I, [_VP, _I, C.POINTER(UNetStatsC)]),
     "mi355_unet_profile": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _I64, _VP, C.POINTER(OpProfileC), _I]),
     "mi355_cfm_euler_sample": (_I, [_VP, _VP, _I, _VP, _I, _I, _FP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
@@ -84,6 +87,8 @@ SIGNATURES = {
     "mi355_corrector_step": (_I, [_VP, _VP, _VP, _F, _F, _F, _F, _F, _I, _U64, _U64, _I64, _VP]),
     "mi355_ddim_step": (_I, [_VP, _VP, _F, _F, _F, _I64, _VP]),
     "mi355_replace_mask": (_I, [_VP, _VP, _VP, _F, _I, _F, _F, _I, _U64, _U64, _I64, _VP]),
+    "mi355_guidance_seed": (_I, [_VP, _VP, _VP, _F, _F, _I, _F, _I64, _VP, _VP, _I64, _VP]),
+    "mi355_guidance_update": (_I, [_VP, _VP, _VP, _F, _I, _VP, _I64, _VP]),
     "mi355_clip": (_I, [_VP, _F, _F, _I64, _VP]),
     "mi355_ema_update": (_I, [_VP, _VP, _F, _F, _I64, _VP]),
     "mi355_mse_per_sample": (_I, [_VP, _VP, _VP, C.c_int, _I64, _VP]),
@@ -149,7 +154,7 @@ def check(rc: int, what: str = ""):
 
 def make_config(*, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_ds, channel_mult,
                 conv_resample=True, num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
-                resblock_updown=False, use_new_attention_order=False, dtype=MI355_BF16) -> UNetConfigC:
+                resblock_updown=False, use_new_attention_order=False, dtype=MI355_BF16, differentiable=False) -> UNetConfigC:
     c = UNetConfigC()
     c.image_size, c.in_channels, c.model_channels, c.out_channels = image_size, in_channels, model_channels, out_channels
     c.num_res_blocks = num_res_blocks
@@ -170,4 +175,5 @@ def make_config(*, image_size, in_channels, model_channels, out_channels, num_re
     c.num_heads_upsample = num_heads_upsample
     c.use_scale_shift_norm, c.resblock_updown = int(use_scale_shift_norm), int(resblock_updown)
     c.use_new_attention_order, c.dtype = int(use_new_attention_order), dtype
+    c.differentiable = int(bool(differentiable))
     return c

@@ -30,14 +30,15 @@ def param_inventory(cfg: _lib.UNetConfigC):
 
 
 class UNetEngine:
-    def __init__(self, cfg_kwargs: dict, state_dict: Dict[str, torch.Tensor], device, precision: str = "bf16"):
+    def __init__(self, cfg_kwargs: dict, state_dict: Dict[str, torch.Tensor], device, precision: str = "bf16", differentiable: bool = False):
         if precision not in _PREC:
             raise ValueError(f"precision must be one of {sorted(_PREC)}")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise MI355BackendError(f"UNetEngine needs an MI355X device, got {self.device} (no CPU fallback)")
         self.precision = precision
-        self.cfg = _lib.make_config(dtype=_PREC[precision], **cfg_kwargs)
+        self.differentiable = bool(differentiable)
+        self.cfg = _lib.make_config(dtype=_PREC[precision], differentiable=differentiable, **cfg_kwargs)
         self.L = _lib.lib()
         inv = param_inventory(self.cfg)
         host = []
@@ -109,6 +110,45 @@ class UNetEngine:
         check(self.L.mi355_unet_forward(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
                                         Cc, self._chk(t, "timesteps"), self._chk(out, "out"), B, ws, wsb, self._stream()),
               "mi355_unet_forward")
+        return out
+
+    def vjp(self, grad_out: torch.Tensor, x_channels: Optional[int] = None, out: Optional[torch.Tensor] = None):
+        """(d out / d x)^T grad_out of the LAST forward() on this engine (same batch): the reconstruction-guidance gradient
+        (AD/image_diffusion/sampling.py:154-163).  Needs an engine built with differentiable=True."""
+        if not self.differentiable:
+            raise MI355BackendError("vjp needs an engine built with differentiable=True")
+        B = grad_out.shape[0]
+        Cx = self.out_channels if x_channels is None else int(x_channels)
+        if tuple(grad_out.shape) != (B, self.out_channels, self.image_size, self.image_size):
+            raise ValueError("grad_out must have the shape of the network output")
+        if out is None:
+            out = torch.empty(B, Cx, self.image_size, self.image_size, device=self.device, dtype=torch.float32)
+        ws, wsb = self.workspace(B)
+        check(self.L.mi355_unet_vjp(self.handle, self._chk(grad_out, "grad_out"), self._chk(out, "grad_x"), Cx, B, ws, wsb, self._stream()),
+              "mi355_unet_vjp")
+        return out
+
+    def plan_ops(self):
+        """Diagnostics: the plan as a list of dicts (op kinds: 0 GN, 1 conv, 2 attention, 3 resample, 4 pool-affine, 5 fused attention)."""
+        names = ("kind", "src0", "src1", "dst", "mode", "ks", "cout", "use_pro", "pro_silu", "res", "res_mode", "gn_site", "heads", "ch", "dst_c", "dst_h")
+        buf = (C.c_int32 * 16)()
+        out, i = [], 0
+        while True:
+            n = self.L.mi355_unet_plan_op(self.handle, i, buf)
+            if n < 0:
+                break
+            out.append(dict(zip(names, list(buf))))
+            i += 1
+            if i >= n:
+                break
+        return out
+
+    def read_tensor(self, tensor: int, batch: int, shape, gradient: bool = False):
+        """Diagnostics: activation (or gradient) `tensor` of the last forward (vjp) as NCHW fp32."""
+        out = torch.empty((batch,) + tuple(shape), device=self.device, dtype=torch.float32)
+        ws, wsb = self.workspace(batch)
+        check(self.L.mi355_unet_read_tensor(self.handle, int(tensor), int(gradient), self._chk(out, "out"), batch, ws, wsb, self._stream()),
+              "mi355_unet_read_tensor")
         return out
 
     def profile(self, x: torch.Tensor, t: torch.Tensor, cond: Optional[torch.Tensor] = None):

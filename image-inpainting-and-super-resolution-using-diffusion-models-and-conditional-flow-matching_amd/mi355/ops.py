@@ -87,6 +87,26 @@ class Ops:
                                             int(philox is not None and z is None), seed, off, x.numel(), _stream()))
         return x
 
+    def guidance_seed(self, x, eps, cond, c_recip, c_recipm1, mode, pad_value):
+        """-> (g_eps, g_x): cotangent for the U-Net VJP and the direct-path gradient of the per-sample constraint
+        (mode 0 = Painting.loss with the pad sentinel masked, 1 = HyperResolution.loss; sampling.py:148-160)."""
+        _same(x, eps, "x", "eps")
+        _same(x, cond, "x", "condition")
+        g_eps, g_x = torch.empty_like(x), torch.empty_like(x)
+        check(_lib.lib().mi355_guidance_seed(_req(x, "x"), _req(eps, "eps"), _req(cond, "condition"), float(c_recip), float(c_recipm1),
+                                             int(mode), float(pad_value), x[0].numel(), _req(g_eps, "g_eps"), _req(g_x, "g_x"), x.numel(),
+                                             _stream()))
+        return g_eps, g_x
+
+    def guidance_update_(self, x, g_x, vjp, scale, apply):
+        """update = -scale * (g_x + vjp); x += update when `apply` (the "before" rule).  -> update"""
+        _same(x, g_x, "x", "g_x")
+        _same(x, vjp, "x", "vjp")
+        upd = torch.empty_like(x)
+        check(_lib.lib().mi355_guidance_update(_req(x, "x"), _req(g_x, "g_x"), _req(vjp, "vjp"), float(scale), int(bool(apply)),
+                                               _req(upd, "update"), x.numel(), _stream()))
+        return upd
+
     def clip_(self, x, lo=-1.0, hi=1.0):
         check(_lib.lib().mi355_clip(_req(x, "x"), float(lo), float(hi), x.numel(), _stream()))
         return x

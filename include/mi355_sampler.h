@@ -58,6 +58,7 @@ typedef struct mi355_unet_config {
   int32_t resblock_updown;
   int32_t use_new_attention_order;
   int32_t dtype; /* MI355_F32 | MI355_BF16 */
+  int32_t differentiable; /* 1: keep what mi355_unet_vjp needs (per-site GroupNorm statistics, the qkv tensors, transposed weights) */
 } mi355_unet_config;
 
 typedef struct mi355_unet mi355_unet; /* opaque */
@@ -83,6 +84,21 @@ int64_t mi355_unet_workspace_bytes(const mi355_unet* net, int batch);
  * is folded into the first conv's gather); t: float[B]; out: [B, out_channels, H, W]. */
 int mi355_unet_forward(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels,
                        const float* t, float* out, int batch, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Vector-Jacobian product of the last mi355_unet_forward on this workspace w.r.t. its image input: grad_x = (d out / d x)^T grad_out
+ * (and, when cond was given, nothing for cond).  This is the `grad(constraint)` through the x0 model of the reconstruction-guidance
+ * sampler (AD/image_diffusion/sampling.py:154-163; per-sample losses make vmap(grad) one batched backward pass).
+ * Needs a handle created with cfg.differentiable = 1 and the SAME workspace (it holds the forward's activations).
+ * grad_out: [B, out_channels, H, W]; grad_x: [B, x_channels, H, W] (fp32, NCHW). */
+int mi355_unet_vjp(mi355_unet* net, const float* grad_out, float* grad_x, int x_channels, int batch, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
+/* Diagnostics: the plan's ops (kind, src0, src1, dst, mode, ks, Cout, use_pro, pro_silu, res, res_mode, gn_site, heads, ch, dst C, dst H;
+ * returns the op count) and an activation (or, differentiable plans, its gradient from the last mi355_unet_vjp) as NCHW fp32
+ * [B, C, H, W] - the per-tensor view the reference gives through forward hooks / autograd on AD/image_diffusion/unet.py. */
+int mi355_unet_plan_op(const mi355_unet* net, int index, int32_t fields[16]);
+int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, float* out, int batch, void* workspace, int64_t workspace_bytes,
+                           void* stream);
 
 /* Launch/traffic counters of the last forward (host side bookkeeping, for bench.py's roofline). */
 typedef struct mi355_unet_stats {
@@ -195,6 +211,15 @@ int mi355_ddim_step(float* x, const float* eps, float c_recip, float c_recipm1, 
 /* Replacement mask (sampling.py:225-232): x = where(cond == pad, x, noisy ? sa*cond + sb*z : cond) */
 int mi355_replace_mask(float* x, const float* cond, const float* z, float pad_value, int noisy, float sa, float sb,
                        int use_philox, uint64_t seed, uint64_t offset, int64_t n, void* stream);
+
+/* Reconstruction guidance, elementwise parts (sampling.py:148-172 + likelihoods.py:58-66,138-143 + sde_diffusion.py:220-224):
+ *   seed  : x0 = clip(c_recip x - c_recipm1 eps); g = d loss_n / d x0 (mode 0: Painting.loss, entries with cond == pad_value masked;
+ *           mode 1: HyperResolution.loss = mean squared error over the sample's `per` entries), through the clip;
+ *           g_eps = -c_recipm1 g (cotangent for mi355_unet_vjp), g_x = c_recip g (direct path of predict_start_from_noise)
+ *   update: u = -scale (g_x + vjp); update <- u; if apply: x += u   ("before" rule; "after" adds `update` to the next state) */
+int mi355_guidance_seed(const float* x, const float* eps, const float* cond, float c_recip, float c_recipm1, int mode, float pad_value,
+                        int64_t elems_per_sample, float* g_eps, float* g_x, int64_t n, void* stream);
+int mi355_guidance_update(float* x, const float* g_x, const float* vjp, float scale, int apply, float* update, int64_t n, void* stream);
 
 /* clip(x, lo, hi) in place, NaN-propagating like torch.clip (sampling.py:13-14) */
 int mi355_clip(float* x, float lo, float hi, int64_t n, void* stream);

@@ -215,9 +215,9 @@ def _run_layers(sd, cfg: UNetConfig, prefix: str, layers: Sequence[tuple], h: to
     return h
 
 
-@torch.no_grad()
-def unet_forward(sd: Dict[str, torch.Tensor], cfg: UNetConfig, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
-    """UNetModel.forward (unet.py:708-728), fp32."""
+def unet_forward_diff(sd: Dict[str, torch.Tensor], cfg: UNetConfig, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+    """UNetModel.forward (unet.py:708-728), fp32, transparent to torch.autograd (the reconstruction-guidance oracle
+    differentiates through it; `unet_forward` below is the same function under no_grad)."""
     input_blocks, middle, output_blocks, _ = build_plan(cfg)
     temb = timestep_embedding(timesteps, cfg.model_channels)
     emb = F.linear(temb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
@@ -233,6 +233,12 @@ def unet_forward(sd: Dict[str, torch.Tensor], cfg: UNetConfig, x: torch.Tensor, 
         h = _run_layers(sd, cfg, f"output_blocks.{i}", layers, h, emb)
     h = F.silu(group_norm32(h, sd["out.0.weight"], sd["out.0.bias"]))
     return _conv(sd, "out.2", h)
+
+
+@torch.no_grad()
+def unet_forward(sd: Dict[str, torch.Tensor], cfg: UNetConfig, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+    """UNetModel.forward (unet.py:708-728), fp32, inference (no autograd graph)."""
+    return unet_forward_diff(sd, cfg, x, timesteps)
 
 
 def model_fn(sd, cfg: UNetConfig):

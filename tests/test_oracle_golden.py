@@ -231,3 +231,53 @@ def test_likelihoods(golden):
         torch.testing.assert_close(cond, g.t(f"{name}/cond"), rtol=0, atol=0)
         torch.testing.assert_close(cfm_ref.painting_loss(randn(5002, 3, 3, 32, 32), cond), g.t(f"{name}/loss"), **TOL)
     torch.testing.assert_close(cfm_ref.hyperresolution_condition(g.t("hyper/img"), 16, 16), g.t("hyper/cond"), **TOL)
+
+
+def _vjp_names(golden):
+    return list(golden("unet_vjp").json("names"))
+
+
+def test_oracle_unet_vjp(golden):
+    """The oracle's functional U-Net under torch.autograd against the reference's UNetModel under torch.autograd:
+    (d out / d x)^T g - the gradient `vmap(grad(constraint))` needs (sampling.py:154-163)."""
+    from image_diffusion.unet import param_shapes
+
+    g = golden("unet_vjp")
+    for name in _vjp_names(golden):
+        cfg = cfg_from_json(g.json(f"{name}/config"))
+        sd = synth_state_dict(param_shapes(cfg), int(g[f"{name}/seed"]))
+        x = g.t(f"{name}/x").clone().requires_grad_()
+        y = unet_ref.unet_forward_diff(sd, cfg, x, g.t(f"{name}/t"))
+        (gx,) = torch.autograd.grad((y * g.t(f"{name}/g")).sum(), x)
+        torch.testing.assert_close(y.detach(), g.t(f"{name}/y"), rtol=2e-4, atol=5e-5)
+        ref = g.t(f"{name}/gx")
+        torch.testing.assert_close(gx, ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()))
+
+
+def test_oracle_recon_guidance(golden):
+    """oracle/ddpm_ref.recon_guidance_sample (autograd of the summed per-sample losses) against the golden driven by the
+    reference's real UNetModel / DDPM / likelihood.loss with its own torch.func.vmap(grad(constraint)) (sampling.py:136-206)."""
+    from image_diffusion.unet import param_shapes
+
+    g = golden("recon_guidance_tiny")
+    Ns = int(g["Ns"])
+    cfg = UNetConfig(16, 1, 32, 1, 1, (2,), channel_mult=(1, 2), num_heads=2)
+    sd = synth_state_dict(param_shapes(cfg), int(g["net_seed"]))
+    eps = ddpm_ref.make_eps_model(lambda x, t: unet_ref.unet_forward_diff(sd, cfg, x, t), Ns)   # autograd-transparent
+    # the constraint gradient at fixed points (no sampler dynamics): autograd of the summed per-sample losses == vmap(grad)
+    d = ddpm_ref.DDPMRef(Ns)
+    x0_model = ddpm_ref._x0_model(eps, d, False, None)
+    for lname, lossf in (("paint", lambda a, b: ddpm_ref.painting_loss(a, b, -2.0)), ("hyper", ddpm_ref.hyperres_loss)):
+        for i in (18, 12, 3):
+            xr = g.t(f"probe/{lname}/i{i}/xi").clone().requires_grad_()
+            (gr,) = torch.autograd.grad(lossf(x0_model(xr, i), g.t(f"probe/{lname}/cond")).sum(), xr)
+            ref = g.t(f"probe/{lname}/i{i}/grad")
+            torch.testing.assert_close(gr, ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()))
+    for tag in ("paint_before", "paint_after", "paint_half_corr1", "hyper_before"):
+        noise = NoiseLog(int(g[f"{tag}/noise_base"]))
+        x0 = ddpm_ref.recon_guidance_sample(eps, Ns, g.t(f"{tag}/xT"), g.t(f"{tag}/cond"), lambda shape: noise(shape),
+                                            gamma=float(g[f"{tag}/gamma"]), start_fraction=float(g[f"{tag}/start_fraction"]),
+                                            update_rule=str(g[f"{tag}/rule"]), n_corrector=int(g[f"{tag}/n_corrector"]), delta=0.1,
+                                            loss=str(g[f"{tag}/loss"]))
+        assert noise.k == int(g[f"{tag}/draws"])
+        torch.testing.assert_close(x0, g.t(f"{tag}/x0"), rtol=2e-3, atol=1e-3)

@@ -379,6 +379,110 @@ def g_samplers():
     save("samplers_tiny", **out)
 
 
+def g_unet_vjp():
+    """Vector-Jacobian products (d out / d x)^T g of the reference's real UNetModel under torch.autograd, the quantity
+    `vmap(grad(constraint))` needs (sampling.py:154-163): input x, times t, cotangent g -> expected gradient."""
+    out = {}
+    cases = {"tiny_in1": 2101, "tiny_in3": 2103, "tiny_film_updown_neworder": 2105, "tiny_noconvresample": 2106, "mnist": 2110, "cifar": 2134,
+             "flowers_in3": 2136}
+    kws = dict(UNET_CASES)
+    kws["flowers_in3"] = (dict(UNET_CASES["flowers_in6"][0], in_channels=3), 1, 1236)
+    names = []
+    for name, gseed in cases.items():
+        kw, B, seed = kws[name]
+        net = load_synth(make_unet(**kw), seed)
+        x = randn(seed + 50000, B, kw["in_channels"], kw["image_size"], kw["image_size"])
+        t = torch.tensor([0.37, 0.91, 0.0, 1.0][:B])
+        g = randn(gseed, B, kw["out_channels"], kw["image_size"], kw["image_size"])
+        with torch.enable_grad():
+            xr = x.clone().requires_grad_()
+            y = net(xr, t)
+            (gx,) = torch.autograd.grad((y * g).sum(), xr)
+        out[f"{name}/x"], out[f"{name}/t"], out[f"{name}/g"], out[f"{name}/gx"], out[f"{name}/y"] = x, t, g, gx, y.detach()
+        out[f"{name}/config"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}
+        out[f"{name}/seed"] = np.int64(seed)
+        names.append(name)
+    out["names"] = names
+    save("unet_vjp", **out)
+
+
+def g_recon_guidance():
+    """Reconstruction-guidance sampler (sampling.py:136-206) around the reference's real UNetModel, DDPM methods and
+    Painting.loss / HyperResolution.loss, with the reference's own torch.func.vmap(grad(constraint)) gradient; only the loop is
+    restated (sampling.py needs the un-vendored plum).  Both update rules, start_fraction 1.0 and 0.5, one corrector case."""
+    from torch.func import grad, vmap
+
+    Ns, B = 25, 2
+    d = ref.sde_diffusion.DDPM(Ns)
+    net = tiny_net(1, 1, 1001)
+    pad = ref.likelihoods.InPainting(patch_size=6, pad_value=-2)
+    hyper = ref.likelihoods.HyperResolution(4, 4)
+    img = rand_uniform(6002, -1, 1, B, 1, 16, 16)
+    cond_paint = img.clone()
+    cond_paint[:, :, 5:11, 4:10] = -2.0
+    cond_hyper = hyper.sample(img)
+    xT = randn(6003, B, 1, 16, 16)
+
+    def x0_model(xi, i):
+        bt = i if torch.is_tensor(i) else torch.full((xi.shape[0],), i, dtype=torch.long)
+        eps = net(xi, 1.0 * bt / d.Ns)
+        return torch.clip(d.predict_start_from_noise(xi, bt, eps), -1, 1)
+
+    out = {"Ns": np.int64(Ns), "net_seed": np.int64(1001)}
+    # gamma: the update is gamma * alpha_i (1 - alpha_i) * x_grad with x_grad ~ sqrt_recip_alphas_cumprod[i] * 2 (x0 - y) (up to 2e3 at
+    # the first steps): with UNTRAINED (synthetic) weights larger values make the guided chain chaotic (a 1e-7 difference ends
+    # anywhere in [-1, 1]), which would pin nothing; these keep it contractive while moving x0 by O(0.1)
+    cases = [("paint_before", pad, cond_paint, 0.02, 1.0, "before", 0), ("paint_after", pad, cond_paint, 0.02, 1.0, "after", 0),
+             ("paint_half_corr1", pad, cond_paint, 3.0, 0.5, "before", 1), ("hyper_before", hyper, cond_hyper, 1.0, 1.0, "before", 0)]
+    # the gradient itself at fixed points (pure function of (xi, i, y)): the chain-rule pieces without any sampler dynamics
+    for lname, lik, condition in (("paint", pad, cond_paint), ("hyper", hyper, cond_hyper)):
+        for i in (18, 12, 3):
+            bt = torch.full((B,), i, dtype=torch.long)
+            xi = xT * float(d.sqrt_one_minus_alphas_cumprod[i]) + img * float(d.sqrt_alphas_cumprod[i])   # a plausible x_i
+            def constraint(x1, i1, y1, lik=lik):
+                x0 = x0_model(x1.unsqueeze(0), i1.unsqueeze(0))
+                return lik.loss(x0, y1.unsqueeze(0)).squeeze(0) if lik is pad else lik.loss(x0, y1.unsqueeze(0))
+            with torch.enable_grad():
+                out[f"probe/{lname}/i{i}/grad"] = vmap(grad(constraint, argnums=0))(xi.clone(), bt, condition).detach()
+            out[f"probe/{lname}/i{i}/xi"] = xi
+        out[f"probe/{lname}/cond"] = condition
+    for k, (tag, lik, condition, gamma, sf, rule, ncorr) in enumerate(cases):
+        noise = NoiseLog(610000 + 10000 * k)
+        xi = xT.clone()
+        first_grad = None
+        for i in reversed(range(Ns)):
+            bt = torch.full((B,), i, dtype=torch.long)
+            x_update = 0.0
+            if i < int(Ns * sf):
+                def constraint(x1, i1, y1):
+                    x0 = x0_model(x1.unsqueeze(0), i1.unsqueeze(0))
+                    return lik.loss(x0, y1.unsqueeze(0)).squeeze(0) if lik is pad else lik.loss(x0, y1.unsqueeze(0))
+                with torch.enable_grad():
+                    x_grad = vmap(grad(constraint, argnums=0))(xi.detach().clone(), bt, condition)
+                if first_grad is None:
+                    first_grad = x_grad.detach().clone()
+                alpha_i = d.alphas[i]
+                x_update = -(gamma * alpha_i * (1 - alpha_i)) * x_grad
+                if rule == "before":
+                    xi = xi + x_update
+            x0_pred = x0_model(xi, bt)
+            mean, var, logvar, _ = d.p_mean_variance(x0_pred, x=xi, i=bt)
+            z = noise(xi) if i > 0 else 0.0
+            pred = mean + (0.5 * logvar).exp() * z
+            if rule == "after":
+                pred = pred + x_update
+            xi = pred
+            for _ in range(ncorr):
+                score = d.score_from_x0(x0_model(xi, bt), bt)
+                dt = (d.tmax - d.tmin) / d.Ns
+                xi = xi + 0.5 * dt * 0.1 * score + math.sqrt(dt * 0.1) * noise(xi)
+        out[f"{tag}/xT"], out[f"{tag}/cond"], out[f"{tag}/x0"], out[f"{tag}/first_grad"] = xT, condition, torch.clip(xi, -1, 1), first_grad
+        out[f"{tag}/gamma"], out[f"{tag}/start_fraction"], out[f"{tag}/n_corrector"] = np.float64(gamma), np.float64(sf), np.int64(ncorr)
+        out[f"{tag}/noise_base"], out[f"{tag}/draws"], out[f"{tag}/rule"] = np.int64(noise.base), np.int64(noise.k), rule
+        out[f"{tag}/loss"] = "painting" if lik is pad else "hyperres"
+    save("recon_guidance_tiny", **out)
+
+
 def g_likelihoods():
     out = {}
     img = rand_uniform(5001, -1, 1, 3, 3, 32, 32)
@@ -405,7 +509,7 @@ def g_likelihoods():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     gens = [g_timestep_embedding, g_ddpm_tables, g_groupnorm, g_resblock, g_attention, g_updown, g_unets, g_euler,
-            g_ddpm_steps, g_samplers, g_likelihoods]
+            g_ddpm_steps, g_samplers, g_likelihoods, g_unet_vjp, g_recon_guidance]
     for g in gens:
         if not only or g.__name__ in only:
             g()
