@@ -288,3 +288,68 @@ def test_frechet_proxy_properties():
     assert f.shape == (600, 256) and torch.equal(f, evaluation.random_conv_features(imgs, seed=0))
     darker = (imgs.float() * 0.8).to(torch.uint8)
     assert evaluation.frechet_proxy(imgs[:300], imgs[300:]) < evaluation.frechet_proxy(imgs[:300], darker[300:])
+
+
+_DOPRI_WORKER = r'''
+import os, sys
+sys.path.insert(0, {pkg!r})
+import torch
+from mi355 import dist as mdist
+from mi355.ode import Dopri5
+
+
+class CpuOps:
+    """torch stand-in for the three HIP stage kernels (host logic under test: the controller and its ONE exchange)."""
+    def rk_combine(self, out, y0, ks, coeffs):
+        acc = torch.zeros_like(ks[0])
+        for k, c in zip(ks, coeffs):
+            acc = acc + k * float(c)
+        out.copy_(acc if y0 is None else y0 + acc)
+        return out
+    def rk_sqnorm(self, acc, a, sub=None, b=None, b2=None, atol=1.0, rtol=0.0):
+        num = a if sub is None else a - sub
+        den = torch.full_like(a, atol)
+        if b is not None:
+            m = b.abs() if b2 is None else torch.max(b.abs(), b2.abs())
+            den = atol + rtol * m
+        acc += (num / den).double().pow(2).sum()
+        return acc
+    def rk_interp(self, out, y0, y1, ym, f0, f1, dt, x):
+        a = 2 * dt * (f1 - f0) - 8 * (y1 + y0) + 16 * ym
+        b = dt * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * ym
+        c = dt * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * ym
+        out.copy_((((a * x + b) * x + c) * x + dt * f0) * x + y0)
+        return out
+
+
+rank, world, local = mdist.init_from_env("gloo")
+g = torch.Generator().manual_seed(3)
+full = torch.randn(6, 5, generator=g)
+A = torch.randn(5, 5, generator=g) * 0.7
+# rows decay at very different rates, so a per-shard error norm would pick different steps on the two ranks
+scale = torch.tensor([0.1, 0.3, 1.0, 3.0, 9.0, 27.0]).reshape(6, 1)
+f = lambda t, y, s: [torch.tanh(y[0] @ A) * s - 0.5 * y[0] * s]
+lo, hi = mdist.shard_range(6)
+single = Dopri5(lambda t, y: f(t, y, scale), 1e-5, 1e-5, ops=CpuOps(), sync_norm=False)
+want = single.integrate([full], 0.0, 1.0)[0]
+sharded = Dopri5(lambda t, y: f(t, y, scale[lo:hi]), 1e-5, 1e-5, ops=CpuOps(), sync_norm=True)
+got = sharded.integrate([full[lo:hi].clone()], 0.0, 1.0)[0]
+assert sharded.n_steps == single.n_steps and sharded.nfe == single.nfe, (rank, sharded.n_steps, single.n_steps)
+assert torch.allclose(got, want[lo:hi], rtol=1e-6, atol=1e-7), (rank, (got - want[lo:hi]).abs().max())
+mdist.barrier()
+print("rank", rank, "ok", sharded.n_steps)
+'''
+
+
+def test_dopri5_error_norm_allreduce_world2_gloo(tmp_path):
+    """The adaptive path's one real exchange (mi355/ode.py Dopri5._norm): with the batch sharded over two ranks the error norm is
+    all-reduced, so both ranks take the SAME accept / reject decisions and step sizes as the single-rank solve of the full batch
+    (torchdiffeq's norm runs over the whole batch: cifar10/compute_fid.py:80-85)."""
+    script = tmp_path / "w.py"
+    script.write_text(_DOPRI_WORKER.format(pkg=PKG))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o
