@@ -81,7 +81,7 @@ def test_cfg2_b256_forward_and_euler_vs_oracle(precision):
 # ---- (b) the persistent conv's concat / residual / emb paths at op level ---------------------------------------------------------
 
 WS_CASES = [
-    # B, C0, C1, H, Cout, resample, gn+silu, emb, res_mode      (all >= 512 workgroups of 128 x 128 => conv3x3_ws_kernel)
+    # B, C0, C1, H, Cout, resample, gn+silu, emb, res_mode      (16x16 and 32x32 cases: >= 512 workgroups of 128 x 128 => conv3x3_ws_kernel)
     (128, 256, 128, 16, 256, 0, True, True, 0),    # output_blocks ResBlock in_layers: GN(cat(h, skip)) + SiLU, conv, + emb
     (128, 256, 256, 16, 256, 0, True, True, 0),    # 512 -> 256 @ 16x16
     (128, 256, 0, 16, 256, 0, True, False, 1),     # ResBlock out_layers: GN + SiLU, conv, + skip (RES_SAME)
@@ -89,6 +89,8 @@ WS_CASES = [
     (64, 128, 0, 32, 128, 0, True, False, 2),      # ResBlock(up=True) out_layers: residual = nearest x2 of the half-size x (RES_UP2)
     (64, 128, 0, 16, 128, 2, True, True, 0),       # ResBlock(up=True) in_layers: conv over nearest x2 of SiLU(GN(x)), + emb
     (64, 128, 0, 32, 256, 0, False, True, 1),      # no prologue, two channel tiles, emb + residual
+    (256, 256, 0, 8, 256, 0, False, True, 1),      # 8x8 level at the bench batch: emb + residual per image
+    (255, 128, 128, 8, 256, 0, True, True, 1),     # the same with per-image GN prologue, concat, odd batch
 ]
 
 

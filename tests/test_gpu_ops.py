@@ -65,6 +65,8 @@ CONV_CASES = [
     (64, 128, 16, 16, 128, 3, 1, 2),  # nearest x2 gather
     (80, 64, 28, 28, 128, 3, 1, 0),   # ragged tiles, tile count not a multiple of the persistent grid
     (16, 64, 64, 64, 128, 3, 1, 0),   # 4 x 4 tiles per image (BASELINE cfg 4 / 5 image sizes)
+    (256, 64, 8, 8, 256, 3, 1, 0),    # bench-sized 8x8 level
+    (255, 128, 8, 8, 256, 3, 1, 0),   # odd batch
 ]
 
 
