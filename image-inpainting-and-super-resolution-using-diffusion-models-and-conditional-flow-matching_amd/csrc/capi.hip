@@ -14,6 +14,13 @@ inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 }  // namespace
 
+// The sampler loops know every step time in advance: all emb_layers outputs of up to EMB_TABLE_STEPS steps are computed by four
+// launches before the loop instead of four launches per step (longer schedules fall back to the per-step path).
+constexpr int EMB_TABLE_STEPS = 1024;
+static size_t emb_table_bytes(const mi355_unet* net) {
+  return al256((size_t)EMB_TABLE_STEPS * 4) + al256((size_t)EMB_TABLE_STEPS * ((size_t)net->emb_total + 9 * (size_t)net->cfg.model_channels) * 4);
+}
+
 extern "C" {
 
 int mi355_version(void) { return 100; }
@@ -53,9 +60,9 @@ void mi355_unet_destroy(mi355_unet* net) { delete net; }
 
 int64_t mi355_unet_workspace_bytes(const mi355_unet* net, int batch) {
   if (!net || batch <= 0) { mi355_set_error("bad argument"); return -1; }
-  // + sampler scratch: t[B], eps/v [B,Cout,H,W], none_like [B,Cin,H,W]
+  // + sampler scratch: t[B], eps/v [B,Cout,H,W], none_like [B,Cin,H,W], and the per-step time-embedding table of the sampler loops
   const size_t hw = (size_t)net->cfg.image_size * net->cfg.image_size;
-  const size_t scratch = al256((size_t)batch * 4) + 2 * al256((size_t)batch * 32 * hw * 4);
+  const size_t scratch = al256((size_t)batch * 4) + 2 * al256((size_t)batch * 32 * hw * 4) + emb_table_bytes(net);
   return unet_workspace_bytes(net, batch) + (int64_t)scratch;
 }
 
@@ -142,9 +149,19 @@ int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const fl
 
 // ---- sampler loops --------------------------------------------------------------------------------
 
-struct Scratch { float* t; float* v; float* none; char* unet_ws; int64_t unet_bytes; };
+struct Scratch { float* t; float* v; float* none; float* tsteps; float* embtab; char* unet_ws; int64_t unet_bytes; };
 // every image of a sampler step shares the step time: the engine computes ONE embedding row (stride-0 broadcast)
 static UnetRun uniform_t_run() { UnetRun r; r.t_uniform = 1; return r; }
+// table[k] = emb_layers outputs for step time t_host[k] (k < n <= EMB_TABLE_STEPS); returns the table or null (per-step path)
+static int make_emb_table(const mi355_unet* net, const Scratch& sc, const float* t_host, int n, hipStream_t s, const float** table) {
+  *table = nullptr;
+  if (n <= 0 || n > EMB_TABLE_STEPS) return 0;
+  MI355_CHECK_HIP(hipMemcpyAsync(sc.tsteps, t_host, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  float* scratch = sc.embtab + (size_t)EMB_TABLE_STEPS * net->emb_total;
+  if (int rc = unet_embedding_table(net, sc.tsteps, n, sc.embtab, scratch, s)) return rc;
+  *table = sc.embtab;
+  return 0;
+}
 static int carve(mi355_unet* net, int B, void* workspace, int64_t workspace_bytes, Scratch& sc) {
   MI355_REQUIRE(net && workspace, -1, "null argument");
   MI355_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, -1, "workspace must be 256-byte aligned");
@@ -154,6 +171,8 @@ static int carve(mi355_unet* net, int B, void* workspace, int64_t workspace_byte
   sc.t = reinterpret_cast<float*>(p); p += al256((size_t)B * 4);
   sc.v = reinterpret_cast<float*>(p); p += al256((size_t)B * 32 * hw * 4);
   sc.none = reinterpret_cast<float*>(p); p += al256((size_t)B * 32 * hw * 4);
+  sc.tsteps = reinterpret_cast<float*>(p); p += al256((size_t)EMB_TABLE_STEPS * 4);
+  sc.embtab = reinterpret_cast<float*>(p); p += al256((size_t)EMB_TABLE_STEPS * ((size_t)net->emb_total + 9 * (size_t)net->cfg.model_channels) * 4);
   sc.unet_ws = p;
   sc.unet_bytes = workspace_bytes - (p - reinterpret_cast<char*>(workspace));
   return 0;
@@ -166,8 +185,10 @@ int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const floa
   MI355_REQUIRE(x_channels == net->cfg.out_channels, -2, "cfm_euler_sample: the vector field must have the state's channel count");
   Scratch sc;
   if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
-  const UnetRun run = uniform_t_run();
+  UnetRun run = uniform_t_run();
   hipStream_t s = S(stream);
+  const float* emb_table = nullptr;
+  if (int rc = make_emb_table(net, sc, t_span_host, n_t - 1, s, &emb_table)) return rc;
   const int64_t n = (int64_t)batch * x_channels * net->cfg.image_size * net->cfg.image_size;
   const int64_t nc = (int64_t)batch * cond_channels * net->cfg.image_size * net->cfg.image_size;
   if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -184,7 +205,8 @@ int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const floa
   for (int k = 0; k + 1 < n_t; ++k) {
     const float t = t_span_host[k], dt = t_span_host[k + 1] - t_span_host[k];
     int rc;
-    if ((rc = fill_launch(sc.t, t, batch, s))) return rc;
+    if (emb_table) run.emb_row = emb_table + (size_t)k * net->emb_total;
+    else if ((rc = fill_launch(sc.t, t, batch, s))) return rc;
     if ((rc = unet_forward(net, x, x_channels, cond, cond_channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s, run))) return rc;
     if ((rc = euler_step_launch(x, sc.v, dt, n, s))) return rc;
     if (cdrift && (rc = euler_step_launch(cdrift, cdrift, dt, nc, s))) return rc;
@@ -206,11 +228,18 @@ int mi355_ddpm_sample(mi355_unet* net, float* x, int channels, const float* cond
   MI355_REQUIRE(mode != MI355_DDPM_AMORTIZED || (amortized && cond), -2, "ddpm_sample: amortized needs a 2C-input net and a condition");
   Scratch sc;
   if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
-  const UnetRun run = uniform_t_run();
+  UnetRun run = uniform_t_run();
   hipStream_t s = S(stream);
   const int64_t n = (int64_t)batch * channels * net->cfg.image_size * net->cfg.image_size;
   const int64_t n_al = (n + 3) / 4 * 4;
   int rc;
+  const float* emb_table = nullptr;   // row i = step i (time i / Ns)
+  if (Ns <= EMB_TABLE_STEPS) {
+    std::vector<float> th((size_t)Ns);
+    for (int i = 0; i < Ns; ++i) th[i] = (float)i / (float)Ns;
+    if ((rc = make_emb_table(net, sc, th.data(), Ns, s, &emb_table))) return rc;
+    MI355_CHECK_HIP(hipStreamSynchronize(s));   // `th` is a temporary host buffer (once per sample() call)
+  }
   if (amortized && (rc = fill_launch(sc.none, opt->none_value, n, s))) return rc;
   // the net's condition input on predictor steps / on corrector steps (the reference's corrector calls
   // x0_model without the condition, sampling.py:116 -> none_like)
@@ -233,7 +262,8 @@ int mi355_ddpm_sample(mi355_unet* net, float* x, int channels, const float* cond
       if ((rc = replace_mask_launch(x, cond, z, opt->pad_value, opt->noise_condition, tb->sqrt_alphas_cumprod[i],
                                     tb->sqrt_one_minus_alphas_cumprod[i], ph, opt->seed, off, n, s))) return rc;
     }
-    if ((rc = fill_launch(sc.t, tval, batch, s))) return rc;
+    if (emb_table) run.emb_row = emb_table + (size_t)i * net->emb_total;
+    else if ((rc = fill_launch(sc.t, tval, batch, s))) return rc;
     if ((rc = unet_forward(net, x, channels, cond_pred, channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s, run))) return rc;
     if (mode == MI355_DDIM) {
       if ((rc = ddim_step_launch(x, sc.v, tb->sqrt_recip_alphas_cumprod[i], tb->sqrt_recipm1_alphas_cumprod[i],

@@ -112,19 +112,25 @@ __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restri
   }
 }
 
+// One thread = one 16-byte channel fragment of one pixel (a pixel's fragments are adjacent threads: full-line NHWC stores; the
+// NCHW reads of a channel are contiguous across the pixels of neighbouring thread groups).  Cpad is a multiple of the fragment.
 template <typename T>
-__global__ void pack_nhwc_kernel(const float* x, int Cx, const float* cond, int Cc, int N, int HW, int Cpad, T* out) {
+__global__ void __launch_bounds__(256) pack_nhwc_kernel(const float* x, int Cx, const float* cond, int Cc, int N, int HW, int Cpad, T* out) {
+  constexpr int V = Elem<T>::VEC;
+  const int G = Cpad / V;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)N * HW * Cpad;
-  if (idx >= total) return;
-  const int c = idx % Cpad;
-  const size_t pix = idx / Cpad;
+  if (idx >= (size_t)N * HW * G) return;
+  const int g = idx % G;
+  const size_t pix = idx / G;
   const int hw = pix % HW;
   const size_t n = pix / HW;
-  float v = 0.f;
-  if (c < Cx) v = x[(n * Cx + c) * HW + hw];
-  else if (c < Cx + Cc) v = cond[(n * Cc + (c - Cx)) * HW + hw];
-  out[idx] = (T)v;
+  float v[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c = g * V + j;
+    v[j] = c < Cx ? x[(n * Cx + c) * HW + hw] : (c < Cx + Cc ? cond[(n * Cc + (c - Cx)) * HW + hw] : 0.f);
+  }
+  *reinterpret_cast<u32x4*>(out + pix * Cpad + g * V) = float_to_frag(v, T());
 }
 
 template <typename T>
@@ -186,7 +192,9 @@ int linear_launch(const float* in, const float* Wt, const float* bias, float* ou
 
 int pack_nhwc_launch(int dtype, const float* x, int Cx, const float* cond, int Cc, int N, int HW, int Cpad, void* out,
                      hipStream_t s) {
-  const size_t total = (size_t)N * HW * Cpad;
+  const int V = dtype == 0 ? 4 : 8;
+  MI355_REQUIRE(Cpad % V == 0, -2, "pack_nhwc: padded channels must be whole 16-byte fragments");
+  const size_t total = (size_t)N * HW * (Cpad / V);
   if (dtype == 0) hipLaunchKernelGGL(pack_nhwc_kernel<float>, grid1d(total, 256), dim3(256), 0, s, x, Cx, cond, Cc, N, HW, Cpad, (float*)out);
   else hipLaunchKernelGGL(pack_nhwc_kernel<bf16>, grid1d(total, 256), dim3(256), 0, s, x, Cx, cond, Cc, N, HW, Cpad, (bf16*)out);
   MI355_CHECK_HIP(hipGetLastError());

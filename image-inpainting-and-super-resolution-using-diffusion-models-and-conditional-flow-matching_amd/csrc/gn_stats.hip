@@ -151,8 +151,17 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(GnFinArgs p) {
     const bool first = q < Q0;
     const float* base = first ? p.st0 + ((size_t)n * p.slots0 * Q0 + q) * 2 : p.st1 + ((size_t)n * p.slots1 * Q1 + (q - Q0)) * 2;
     const int slots = first ? p.slots0 : p.slots1, stride = (first ? Q0 : Q1) * 2;
+    // slots summed in a fixed order, eight independent loads in flight (a dependent chain of L2 round trips is all this kernel is)
     float s = 0.f, sq = 0.f;
-    for (int k = 0; k < slots; ++k) {
+    int k = 0;
+    for (; k + 8 <= slots; k += 8) {
+      f32x2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2*>(base + (size_t)(k + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += v[u][0]; sq += v[u][1]; }
+    }
+    for (; k < slots; ++k) {
       const f32x2 v = *reinterpret_cast<const f32x2*>(base + (size_t)k * stride);
       s += v[0]; sq += v[1];
     }

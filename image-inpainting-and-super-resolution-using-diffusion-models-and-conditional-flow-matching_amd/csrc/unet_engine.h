@@ -68,6 +68,8 @@ struct mi355_unet {
 // handle may be driven from several host threads / streams (each with its own workspace).
 struct UnetRun {
   int t_uniform = 0;   // sampler loops: t[0] holds for the whole batch (one embedding row, stride-0 broadcast)
+  const float* emb_row = nullptr;   // sampler loops: this step's row of a precomputed table of all emb_layers outputs
+                                    // (unet_embedding_table): the four time-embedding launches are skipped
   // optional per-op profiling (mi355_unet_profile)
   std::vector<mi355_op_profile>* prof = nullptr;
   std::vector<hipEvent_t>* prof_events = nullptr;
@@ -82,5 +84,8 @@ WsLayout unet_ws_layout(const mi355_unet* net, int B);
 // (d out / d x)^T grad_out of the last unet_forward on this workspace (differentiable plans only; unet_backward.hip)
 int unet_backward(const mi355_unet* net, const float* grad_out, float* grad_x, int Cx, int batch, void* workspace, int64_t workspace_bytes,
                   hipStream_t stream);
+// All emb_layers outputs (UNetModel.time_embed + every ResBlock's emb_layers, unet.py:564-569,293-299) for n step times at once:
+// table [n][emb_total] fp32; scratch = n * 9 * model_channels floats.  The sampler loops know every step time in advance.
+int unet_embedding_table(const mi355_unet* net, const float* t_dev, int n, float* table, float* scratch, hipStream_t stream);
 int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int batch,
                  void* workspace, int64_t workspace_bytes, hipStream_t stream, const UnetRun& run = UnetRun());

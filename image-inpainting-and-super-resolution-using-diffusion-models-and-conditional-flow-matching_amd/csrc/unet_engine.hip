@@ -469,6 +469,19 @@ WsLayout unet_ws_layout(const mi355_unet* net, int B) {
 }
 static WsLayout ws_layout(const mi355_unet* net, int B) { return unet_ws_layout(net, B); }
 
+int unet_embedding_table(const mi355_unet* net, const float* t_dev, int n, float* table, float* scratch, hipStream_t stream) {
+  const int mc = net->cfg.model_channels;
+  const char* W = net->dev_weights;
+  auto WF = [&](size_t off) { return reinterpret_cast<const float*>(W + off); };
+  float* temb = scratch; float* e1 = scratch + (size_t)n * mc; float* e2 = e1 + (size_t)n * 4 * mc;
+  int rc;
+  // emb2 = silu(time_embed(timestep_embedding(t))): the SiLU that opens every emb_layers is applied once here
+  if ((rc = timestep_embedding_launch(t_dev, n, mc, 10000.f, temb, stream))) return rc;
+  if ((rc = linear_launch(temb, WF(net->te_w0), WF(net->te_b0), e1, n, mc, 4 * mc, 0, 1, stream))) return rc;
+  if ((rc = linear_launch(e1, WF(net->te_w2), WF(net->te_b2), e2, n, 4 * mc, 4 * mc, 0, 1, stream))) return rc;
+  return linear_launch(e2, WF(net->emb_w), WF(net->emb_b), table, n, 4 * mc, net->emb_total, 0, 0, stream);
+}
+
 int64_t unet_workspace_bytes(const mi355_unet* net, int batch) { return (int64_t)ws_layout(net, batch).total; }
 
 int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* cond, int Cc, const float* t, float* out, int B,
@@ -497,10 +510,8 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   // time embedding path (fp32): emb2 = silu(time_embed(timestep_embedding(t))) ; embp = all emb_layers linears
   // in the sampler loops every image shares the step time: one embedding row, broadcast with stride 0
   const int Be = run.t_uniform ? 1 : B, estride = run.t_uniform ? 0 : net->emb_total;
-  if ((rc = timestep_embedding_launch(t, Be, mc, 10000.f, F(l.temb), stream))) return rc;
-  if ((rc = linear_launch(F(l.temb), WF(net->te_w0), WF(net->te_b0), F(l.emb1), Be, mc, 4 * mc, 0, 1, stream))) return rc;
-  if ((rc = linear_launch(F(l.emb1), WF(net->te_w2), WF(net->te_b2), F(l.emb2), Be, 4 * mc, 4 * mc, 0, 1, stream))) return rc;
-  if ((rc = linear_launch(F(l.emb2), WF(net->emb_w), WF(net->emb_b), F(l.embp), Be, 4 * mc, net->emb_total, 0, 0, stream))) return rc;
+  const float* embp = run.emb_row ? run.emb_row : F(l.embp);
+  if (!run.emb_row && (rc = unet_embedding_table(net, t, Be, F(l.embp), F(l.temb), stream))) return rc;
   const int S = net->cfg.image_size;
   if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
   { mi355_op_profile r{}; r.kind = MI355_OP_PRELUDE; mark(r); }
@@ -512,7 +523,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       GnFinDesc g; g.stats0 = SP(op.src0); g.slots0 = gn_slots[op.src0]; g.C0 = s0.C;
       if (op.src1 >= 0) { g.stats1 = SP(op.src1); g.slots1 = gn_slots[op.src1]; g.C1 = C1; }
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
-      if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = estride; }
+      if (op.film_emb_off >= 0) { g.film = embp + op.film_emb_off; g.film_stride = estride; }
       g.a = F(l.gna); g.b = F(l.gnb);
       rc = gn_finalize_launch(g, stream);
       r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
@@ -520,7 +531,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     } else if (op.kind == OP_GN) {
       GnDesc g; g.dtype = dtype; g.src0 = TP(op.src0); g.C0 = s0.C; g.src1 = TP(op.src1); g.C1 = C1;
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
-      if (op.film_emb_off >= 0) { g.film = F(l.embp) + op.film_emb_off; g.film_stride = estride; }
+      if (op.film_emb_off >= 0) { g.film = embp + op.film_emb_off; g.film_stride = estride; }
       g.a = F(l.gna); g.b = F(l.gnb);
       if (op.gn_site >= 0) {   // differentiable plan: this site's own (a, b, mean, rstd)
         float* sp = F(l.sites) + net->site_off[op.gn_site] * (size_t)B;
@@ -540,7 +551,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
         c.pro_a = sp; c.pro_b = sp + (size_t)B * net->site_C[op.gn_site];
       }
       c.w = W + op.w_off; c.bias = WF(op.bias_off); c.Cout = op.Cout;
-      if (op.emb_off >= 0) { c.emb = F(l.embp) + op.emb_off; c.emb_stride = estride; }
+      if (op.emb_off >= 0) { c.emb = embp + op.emb_off; c.emb_stride = estride; }
       if (op.res >= 0) { c.res = TP(op.res); c.res_mode = op.res_mode; }
       c.out_mode = op.out_mode;
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
