@@ -37,7 +37,7 @@ def per_kernel(db_path, counter):
 
 def short(name):
     name = re.sub(r"\(.*", "", name)
-    m = re.search(r"(conv3x3_ws_kernel|conv_igemm_kernel|conv1x1_kernel|gn_affine_kernel|attention_kernel|affine_pool_kernel|"
+    m = re.search(r"(attn_fused_kernel|attention_bwd_\w+_kernel|conv3x3_ws_kernel|conv_igemm_kernel|conv1x1_kernel|gn_affine_kernel|gn_finalize_kernel|attention_kernel|affine_pool_kernel|"
                   r"linear_small_kernel|linear_kernel|timestep_embedding_kernel|pack_nhwc_kernel|unpack_nchw_kernel|resample\w*_kernel|ew4\w*|rk_\w+_kernel)", name)
     return m.group(1) if m else name[:60]
 
