@@ -18,6 +18,7 @@
 //     kernel row's weight tiles are loaded into registers while the current row's MFMAs run; weight
 //     tiles are double-buffered in LDS, so there is one barrier per kernel row (48 MFMAs per wave).
 // 4 waves per workgroup, v_mfma_f32_16x16x32_bf16 (or v_mfma_f32_16x16x4_f32 in the fp32 build).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -567,6 +568,7 @@ int launch_cfg(const ConvKArgs& a, int BM, int BN, int ks, int pit, dim3 grid, s
 }
 
 #include "conv_ws.inc.h"
+#include "conv_small.inc.h"
 
 struct Geo {
   int Hc, Wc, Ho, Wo, BM, BN, bn_pack, lvw, lth, G, PW, PH, NP, tiles_x, tiles_y, groups, pad, stride, plane_bytes, pit, pit_t;
@@ -749,6 +751,11 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
     if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); if (gn_slots_used) *gn_slots_used = a.gn_slots; return 0; }
     if (r < 0) return r;
     a.gn_stats = nullptr; a.gn_slots = 0;
+  }
+  {   // 8x8 / 4x4 levels: barrier-free K loop over an LDS-resident patch, weights straight into registers (conv_small.inc.h)
+    const int r = d.dtype == 0 ? launch_small<float>(a, d.ks, stream) : launch_small<bf16>(a, d.ks, stream);
+    if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
+    if (r < 0) return r;
   }
   {
     const int slots = g.tiles_x * g.tiles_y * (g.BN == 32 ? 4 : 2);   // (pixel tile, pixel-wave) per image

@@ -1,0 +1,317 @@
+// 3x3 convolution of the 8x8 and 4x4 levels (included by conv_igemm.hip; same args, same packed weights, same epilogue).
+//
+// At these levels a batch holds few pixels (B = 256: 16k / 4k), so the GEMM is short and wide: every 64-pixel tile needs ALL of
+// the layer's weights (1.2-2.4 MB) and there are only as many tiles as CUs.  The plain kernel's per-row pipeline (stage the
+// patch, stage a weight row, barrier, 24 MFMAs) is then latency-bound in every phase (stamps: DESIGN.md section 6), although the
+// bound itself - the CU's 64 B/clk L1 path streaming the weights, equal to the MFMA time of a 64-pixel tile - is 3x lower.  Here:
+//   * one 4-wave workgroup per 64-pixel tile (one 8x8 image or four 4x4 images, whole images: no halo exchange, zero padding
+//     only); its haloed input patch for ALL channel chunks is staged into LDS once (one barrier), then the K loop has NO barrier;
+//   * the weights never touch LDS: a wave owns 64 output channels, nobody else in the workgroup needs its weight rows, so its B
+//     fragments go global -> VGPR directly (the host-packed tile is already in fragment order: one 1-KB coalesced load per 16
+//     channels) through a register ring one chunk (9 taps) deep - the loads of chunk c + 1 are issued as chunk c's taps retire;
+//   * few tiles (4x4 level): the four waves split K instead of N (KSPLIT = 2 / 4: more workgroups of fewer channels), partial
+//     accumulators meet in LDS and every wave finishes (epilogue) a quarter / half of the pixels;
+//   * LDS image of the patch: dense 64-B pixel rows, 16-B slots XOR-swizzled by the pixel index, row pitch 16 (8x8) / 8 (4x4)
+//     pixels: conflict-free ds_read_b128 for every tap shift (tools/lds_bank_sim.py; the plain kernel's 96-B rows are 2-way
+//     conflicted on 8-pixel-wide images).
+namespace sm {
+struct Args { int pwp, pimg, sh, plane, nphase, chp, red_bytes; };
+}  // namespace sm
+
+template <typename T, int KSPLIT, int NCHP, int PITU>
+__global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Args g) {
+  using E = Elem<T>;
+  constexpr int CHUNK = E::CHUNK, ESZ = sizeof(T);
+  constexpr int NW = 4 / KSPLIT;          // waves along the output channels (64 each); KSPLIT waves share a channel block
+  constexpr int MI = 4, NI = 4, MPW = MI / KSPLIT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kk = wave / NW, wn = wave - kk * NW;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int n0 = blockIdx.x * p.G;
+  const int co0 = ((int)blockIdx.y * NW + wn) * 64;
+  const int VWm = (1 << p.lvw) - 1, THm = (1 << p.lth) - 1;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src1 ? p.src1 : p.src0), 0, p.bytes1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wbytes, 0x00020000);
+
+  // ---- weight stream of this wave: chunk sequence s = 0 .. nphase * chw - 1 ----
+  const int chw = g.chp / KSPLIT;     // chunks per wave and phase: chunk (ph, j) of this wave = ph * chp + kk * chw + j
+  uint32_t boff[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = (co0 & 127) + ni * 16 + lr;
+    boff[ni] = row * 64 + 16 * (lq ^ ((row >> 1) & 3));
+  }
+  const uint32_t wt0 = (uint32_t)(co0 >> 7) * p.nchunks * 9;   // first (chunk, tap) tile of this wave's 128-channel pack tile
+  u32x4 bring[9][NI] = {};
+  auto issue_b = [&](auto tapc, int c) {
+    constexpr int tap = decltype(tapc)::value;
+    const uint32_t so = (wt0 + (uint32_t)c * 9 + tap) * 8192u;
+    if constexpr (WS_ABLATE & 8) return;   // diagnostic builds only (Makefile: variant ABL=<mask>): 4 = no LDS reads / MFMAs, 8 = no weight loads, 16 = no patch staging
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bring[tap][ni] = buf_load16(rsw, boff[ni], so);
+  };
+  {
+    const int c = kk * chw;
+    issue_b(IC<0>(), c); issue_b(IC<1>(), c); issue_b(IC<2>(), c); issue_b(IC<3>(), c); issue_b(IC<4>(), c);
+    issue_b(IC<5>(), c); issue_b(IC<6>(), c); issue_b(IC<7>(), c); issue_b(IC<8>(), c);
+  }
+
+  // ---- patch staging geometry: fragment u of this thread = patch pixel (tid + 256 u) >> 2, 16-B quarter (tid + 256 u) & 3 ----
+  uint32_t voff0[PITU], voff1[PITU]; int ldst[PITU];
+  {
+    const int ppi = p.PH * p.PW, npv = p.G * ppi;
+    const float inv_ppi = 1.0f / (float)ppi, inv_pw = 1.0f / (float)p.PW;
+#pragma unroll
+    for (int u = 0; u < PITU; ++u) {
+      const int i = tid + 256 * u, pp = i >> 2, q = i & 3;
+      int s = -1, dst = -1;
+      if (pp < npv) {
+        const int gi = (int)(((float)pp + 0.5f) * inv_ppi), r = pp - gi * ppi;
+        const int py = (int)(((float)r + 0.5f) * inv_pw), px = r - py * p.PW;
+        const int n = n0 + gi, cy = py - 1, cx = px - 1;
+        if (n < p.N && cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc)
+          s = p.mode == CONV_UP2 ? (n * p.Hs + (cy >> 1)) * p.Ws + (cx >> 1) : (n * p.Hs + cy) * p.Ws + cx;
+        const int lin = gi * g.pimg + py * g.pwp + px;
+        dst = lin * 64 + 16 * (q ^ ((lin >> g.sh) & 3));
+      }
+      ldst[u] = dst;
+      voff0[u] = s >= 0 ? (uint32_t)s * (uint32_t)(p.C0 * ESZ) + q * 16 : p.bytes0;
+      voff1[u] = s >= 0 ? (uint32_t)s * (uint32_t)(p.C1 * ESZ) + q * 16 : p.bytes1;
+    }
+  }
+  auto stage = [&](int ph) {
+    if constexpr (WS_ABLATE & 16) return;
+    u32x4 raw[NCHP][PITU];
+#pragma unroll
+    for (int cl = 0; cl < NCHP; ++cl) {
+      const int cb = (ph * g.chp + cl) * CHUNK;
+      const bool live = cl < g.chp, first = cb < p.C0;
+#pragma unroll
+      for (int u = 0; u < PITU; ++u) {
+        const uint32_t vo = live ? (first ? voff0[u] : voff1[u]) : (first ? p.bytes0 : p.bytes1);
+        raw[cl][u] = buf_load16(first ? rs0 : rs1, vo, (uint32_t)(first ? cb : cb - p.C0) * ESZ);
+      }
+    }
+#pragma unroll
+    for (int cl = 0; cl < NCHP; ++cl) {
+      if (cl < g.chp) {
+#pragma unroll
+        for (int u = 0; u < PITU; ++u)
+          if (ldst[u] >= 0) *reinterpret_cast<u32x4*>(smem + cl * g.plane + ldst[u]) = raw[cl][u];
+      }
+    }
+  };
+
+  // ---- A fragment addresses of the 9 taps (the swizzle follows the shifted pixel, so every tap has its own) ----
+  int aaddr[9][MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = mi * 16 + lr;
+    const int tx = m & VWm, ty = (m >> p.lvw) & THm, gi = m >> (p.lvw + p.lth);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int lin = gi * g.pimg + (ty + t / 3) * g.pwp + tx + t % 3;
+      aaddr[t][mi] = lin * 64 + 16 * (lq ^ ((lin >> g.sh) & 3));
+    }
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ph = 0; ph < g.nphase; ++ph) {
+    if (ph > 0) __syncthreads();         // every wave has finished reading the previous phase's patch
+    stage(ph);
+    __syncthreads();
+    for (int j = 0; j < chw; ++j) {
+      const int c = ph * g.chp + kk * chw + j;
+      // the chunk whose weights replace this one's in the ring; after the last chunk the ring refills with it again (never used)
+      const int cn = j + 1 < chw ? c + 1 : (ph + 1 < g.nphase ? c + 1 + g.chp - chw : c);
+      const char* pl = smem + (kk * chw + j) * g.plane;
+      u32x4 af[2][MI] = {};
+      auto read_a = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (WS_ABLATE & 4) return;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[t & 1][mi] = *reinterpret_cast<const u32x4*>(pl + aaddr[t][mi]);
+      };
+      auto tap = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t < 8) read_a(IC<t + 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WS_ABLATE & 4) { asm volatile("" ::"v"(bring[t][0]), "v"(bring[t][1]), "v"(bring[t][2]), "v"(bring[t][3])); }
+        else
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], bring[t][ni], af[t & 1][mi], T());   // D rows = channels, cols = pixels
+        __builtin_amdgcn_sched_barrier(0);
+        issue_b(tc, cn);
+      };
+      read_a(IC<0>());
+      tap(IC<0>()); tap(IC<1>()); tap(IC<2>()); tap(IC<3>()); tap(IC<4>()); tap(IC<5>()); tap(IC<6>()); tap(IC<7>()); tap(IC<8>());
+    }
+  }
+
+  // ---- split K: partial accumulators meet in LDS; wave kk finishes pixels 16 * MPW * kk .. of the tile ----
+  if constexpr (KSPLIT > 1) {
+    __syncthreads();                     // the patch is dead
+    char* red = smem + ((wn * KSPLIT + kk) * (MI * NI)) * 1024 + lane * 16;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      if (mi / MPW != kk) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(red + (mi * NI + ni) * 1024) = acc[mi][ni];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      if (mi / MPW == kk) {
+#pragma unroll
+        for (int k2 = 0; k2 < KSPLIT; ++k2)
+          if (k2 != kk) {
+            const char* src = smem + ((wn * KSPLIT + k2) * (MI * NI)) * 1024 + lane * 16;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + (mi * NI + ni) * 1024);
+              acc[mi][ni] = f32x4{acc[mi][ni][0] + v[0], acc[mi][ni][1] + v[1], acc[mi][ni][2] + v[2], acc[mi][ni][3] + v[3]};
+            }
+          }
+      }
+  }
+
+  // ---- epilogue (as conv_igemm_kernel's): lane (lr, lq) holds channels 4 lq .. 4 lq + 3 of pixel lr per 16x16 tile ----
+  constexpr bool PAIR = E::DTYPE == 1;
+  constexpr int NP2 = PAIR ? NI / 2 : NI, PSTEP = PAIR ? 32 : 16;
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (p.ablate & 1) ? 0u : p.obytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.out), 0, p.rbytes, 0x00020000);
+  const int co_w = co0 + 4 * lq;
+  const int co_s = PAIR ? co0 + (lq & 1) * 16 + (lq >> 1) * 8 : co_w;
+  f32x4 bias4[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bias4[ni] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co_w + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  auto epi = [&](auto mic) {
+    constexpr int mi = decltype(mic)::value;
+    const int m = mi * 16 + lr;
+    const int tx = m & VWm, ty = (m >> p.lvw) & THm, gi = m >> (p.lvw + p.lth);
+    const int n = n0 + gi;
+    const bool ok = n < p.N && ty < p.Ho && tx < p.Wo;
+    const uint32_t opix = (uint32_t)((n * p.Ho + ty) * p.Wo + tx);
+    const uint32_t ovo = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.obytes;
+    const uint32_t rvo = (ok && p.res_mode != RES_NONE) ? ovo : p.rbytes;
+    u32x4 rr[NP2];
+    if (p.res_mode != RES_NONE) {
+#pragma unroll
+      for (int k = 0; k < NP2; ++k) rr[k] = buf_load16(rsr, rvo + k * PSTEP * ESZ, 0);
+    }
+    f32x4 ad[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      ad[ni] = bias4[ni];
+      if (p.emb) {
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)min(n, p.N - 1) * p.emb_stride + co_w + ni * 16);
+        ad[ni] = f32x4{ad[ni][0] + ev[0], ad[ni][1] + ev[1], ad[ni][2] + ev[2], ad[ni][3] + ev[3]};
+      }
+    }
+    if constexpr (!PAIR) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        f32x4 o = f32x4{acc[mi][ni][0] + ad[ni][0], acc[mi][ni][1] + ad[ni][1], acc[mi][ni][2] + ad[ni][2], acc[mi][ni][3] + ad[ni][3]};
+        if (p.res_mode != RES_NONE) { const f32x4 t = __builtin_bit_cast(f32x4, rr[ni]); o = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]}; }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo + ni * 16 * ESZ, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP2; ++k) {
+        float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.res_mode != RES_NONE) {   // un-swap the 8-channel residual piece back to the accumulator layout
+          const auto s0 = __builtin_amdgcn_permlane16_swap(rr[k][0], rr[k][2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(rr[k][1], rr[k][3], false, false);
+          const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            ra[2 * j] = __builtin_bit_cast(float, xa[j] << 16); ra[2 * j + 1] = __builtin_bit_cast(float, xa[j] & 0xffff0000u);
+            rb[2 * j] = __builtin_bit_cast(float, xb[j] << 16); rb[2 * j + 1] = __builtin_bit_cast(float, xb[j] & 0xffff0000u);
+          }
+        }
+        bf16x4 ta, tb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ta[j] = (bf16)(acc[mi][2 * k][j] + ad[2 * k][j] + ra[j]);
+          tb[j] = (bf16)(acc[mi][2 * k + 1][j] + ad[2 * k + 1][j] + rb[j]);
+        }
+        const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+        const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
+        const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo + k * PSTEP * ESZ, 0, 0);
+      }
+    }
+  };
+  if constexpr (KSPLIT == 1) { epi(IC<0>()); epi(IC<1>()); epi(IC<2>()); epi(IC<3>()); }
+  else if constexpr (KSPLIT == 2) {
+    if (kk == 0) { epi(IC<0>()); epi(IC<1>()); } else { epi(IC<2>()); epi(IC<3>()); }
+  } else {
+    if (kk == 0) epi(IC<0>()); else if (kk == 1) epi(IC<1>()); else if (kk == 2) epi(IC<2>()); else epi(IC<3>());
+  }
+}
+
+// Shapes this kernel takes: 3x3, stride 1 (plain or nearest-x2 input), whole 8x8 / 4x4 output images, no GroupNorm prologue (these
+// levels normalise in a pass of their own), NHWC output with C_out % 128 == 0, residual at the output resolution or none.
+// 0 = launched, 1 = not eligible (the caller goes on to the plain kernel), < 0 = error
+template <typename T>
+int launch_small(const ConvKArgs& a0, int ks, hipStream_t s) {
+  static const int enabled = getenv("MI355_CONV_SMALL") ? atoi(getenv("MI355_CONV_SMALL")) : 1;
+  ConvKArgs a = a0;
+  if (!enabled || ks != 3 || a.stride != 1 || a.out_mode != OUT_NHWC || a.pro_a) return 1;
+  if (a.Ho != a.Wo || (a.Ho != 8 && a.Ho != 4) || a.Cout % 128 != 0) return 1;
+  if (a.res_mode != RES_NONE && a.res_mode != RES_SAME) return 1;
+  constexpr int CH = Elem<T>::CHUNK;
+  if (a.C0 % CH || a.C1 % CH) return 1;
+  const bool w8 = a.Ho == 8;
+  sm::Args g;
+  a.lvw = a.lth = w8 ? 3 : 2;
+  a.G = w8 ? 1 : 4;
+  a.PW = a.PH = a.Ho + 2;
+  g.pwp = w8 ? 16 : 8; g.sh = w8 ? 1 : 2;
+  g.pimg = a.PH * g.pwp;
+  g.plane = (a.G * g.pimg - (g.pwp - a.PW)) * 64;
+  const int nchp = w8 ? 16 : 8;
+  g.nphase = (a.nchunks + nchp - 1) / nchp;
+  g.chp = a.nchunks / g.nphase;
+  if (g.chp * g.nphase != a.nchunks) return 1;
+  const int tiles = (a.N + a.G - 1) / a.G;
+  // waves along N: as many as keep every CU busy (each halving doubles the workgroups and splits K between wave pairs)
+  const int ncu = ws_num_cus();
+  int nw = 4;
+  while (nw > 1 && (long)tiles * (a.Cout / (64 * nw)) < ncu) nw >>= 1;
+  if (a.Cout % (64 * nw)) return 1;
+  const int ksplit = 4 / nw;
+  if (g.chp % ksplit) return 1;
+  g.red_bytes = ksplit > 1 ? 4 * 16 * 1024 : 0;
+  const size_t lds = std::max((size_t)g.chp * g.plane, (size_t)g.red_bytes);
+  if (lds > 160 * 1024) return 1;
+  a.gn_stats = nullptr; a.gn_slots = 0;
+  dim3 grid(tiles, a.Cout / (64 * nw));
+  int rc = 0;
+  auto go = [&](auto kern) {
+    rc = mi355_allow_big_lds(kern, "conv3x3 (small levels)");
+    if (rc == 0) hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, g);
+  };
+  if (w8) {
+    if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 16, 2>);
+    else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 16, 2>);
+    else go(conv3x3_small_kernel<T, 4, 16, 2>);
+  } else {
+    if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 8, 3>);
+    else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 8, 3>);
+    else go(conv3x3_small_kernel<T, 4, 8, 3>);
+  }
+  return rc;
+}

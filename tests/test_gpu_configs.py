@@ -91,6 +91,15 @@ WS_CASES = [
     (64, 128, 0, 32, 256, 0, False, True, 1),      # no prologue, two channel tiles, emb + residual
     (256, 256, 0, 8, 256, 0, False, True, 1),      # 8x8 level at the bench batch: emb + residual per image
     (255, 128, 128, 8, 256, 0, True, True, 1),     # the same with per-image GN prologue, concat, odd batch
+    # 8x8 / 4x4 levels without prologue => conv3x3_small_kernel (LDS-resident patch, weights straight into registers)
+    (256, 256, 256, 8, 256, 0, False, True, 0),    # 512 -> 256 @ 8x8, concat: one workgroup per image, waves split N (fp32: two K phases)
+    (128, 128, 128, 8, 256, 0, False, False, 1),   # fewer tiles than CUs: wave pairs split K
+    (64, 256, 0, 8, 256, 0, False, True, 1),       # all four waves split K
+    (3, 256, 0, 8, 128, 0, False, True, 1),        # tiny batch
+    (256, 256, 0, 4, 256, 0, False, True, 1),      # 4x4 level at the bench batch: four images per tile, split K
+    (255, 256, 256, 4, 256, 0, False, True, 1),    # 512 -> 256 @ 4x4, odd batch (a tile with three images), two K phases
+    (1024, 128, 0, 4, 128, 0, False, True, 0),     # 4x4 with wave pairs splitting K
+    (256, 256, 0, 4, 256, 2, False, False, 0),     # Upsample conv 4x4 -> 8x8 (nearest x2 gather while staging)
 ]
 
 
