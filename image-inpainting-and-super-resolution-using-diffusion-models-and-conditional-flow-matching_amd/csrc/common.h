@@ -119,6 +119,26 @@ int mi355_allow_big_lds(K kern, const char* what) {
   return 0;
 }
 
+// ---- L2 warm-up of the next kernel's weights -----------------------------------------------------------------------------------
+// A layer's packed weights (0.3-4.7 MB) are read by every workgroup of its conv at the same moment, cold from HBM / Infinity Cache:
+// at the 8x8 / 4x4 levels that first touch is 20 % of the launch (in-network 28 us vs 22 us with warm weights).  The memory-bound
+// GroupNorm pass that runs right before such a conv gets one EXTRA wave per workgroup that only touches those weights and exits
+// (loads return in order within a wave, so a working wave would wait for the cold lines before its own data; a wave that has ended
+// does not take part in later barriers).  Workgroup b runs on XCD b % 8 (one L2 each): the extra waves of every XCD cover the whole
+// range once, one 128-B line per lane and step.
+__device__ __forceinline__ void l2_warm_wave(const void* p, uint32_t bytes) {
+  const uint32_t rank = blockIdx.x >> 3, per = (gridDim.x + 7) >> 3, step = per * 64u * 128u;
+  const char* base = reinterpret_cast<const char*>(p);
+  uint32_t off = (rank * 64u + (threadIdx.x & 63)) * 128u;
+  // 16 loads in flight per lane (4 MB per XCD at 256 workgroups; a longer range is warmed partially, a shorter one re-touches line 0).
+  // The destinations stay live until all 16 have landed: a register reused while its load is in flight would be overwritten by it.
+  uint32_t v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i, off += step) v[i] = *reinterpret_cast<const uint32_t*>(base + (off < bytes ? off : 0u));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(v[i]));
+}
+
 // ---- fused GroupNorm statistics: per-wave partial sums from a conv epilogue -------------------------------------------------
 // The reference normalises in a separate pass (GroupNorm32, AD/image_diffusion/nn.py:11-13,87-94); here the conv that PRODUCES a
 // tensor also leaves, per (image, slot, channel quad), the fp32 sum and sum of squares of its final output values

@@ -12,23 +12,35 @@
 //     (tile, chunk, kernel row) items and run ahead of the consumers across tile boundaries:
 //        global loads  : patch fragments and GN (a, b) one chunk (3 rows) ahead in a register ring
 //        LDS commits   : two patch fragments per kernel row, transformed and written one chunk ahead of the consumers
-//                        (2 patch planes); weight rows go global -> LDS by DMA one row ahead (3 row buffers)
-//     ONE workgroup barrier per kernel row;
+//                        (3 patch planes); weight rows go global -> LDS by DMA one row ahead (4 row buffers);
+//   * NO workgroup barrier in the stream (round 2; round 1 had one s_barrier per kernel row, and the stamps showed both roles
+//     waiting at it - 750 / 1080 cycles of a 3.3k-cycle row - because a barrier runs the two streams in lockstep: every row
+//     costs max(loader row, consumer row), and the consumers' epilogue (5.3k cycles per tile) stalls the loaders).  Monotonic
+//     row counters in LDS instead, one per wave (a shared counter would let a fast wave's next row stand in for a slow wave's
+//     current one): a loader wave adds 1 to its `prod` when its share of a kernel row (patch fragments and DMA'd weights) has
+//     landed, a consumer wave adds 1 to its `cons` when its reads of a row have been issued (LDS executes a wave's operations
+//     in order, so the add is performed after them); a consumer starts row R once min(prod) >= R + 1, a loader may overwrite
+//     the buffers of row R - 3 once min(cons) >= R - 2 (one ds_read_b128 fetches all four).  With 4 weight buffers and 3 patch planes the
+//     loaders run up to two rows further ahead than lockstep allowed: row-time variance and the epilogue are absorbed;
 //   * the consumers run a register-double-buffered pipeline of half-taps (16 MFMAs each): the LDS reads of step s+1 are
-//     issued before the MFMAs of step s, and the barrier of the next row sits between the last reads and the last
-//     MFMAs of the current row, so neither LDS latency nor the barrier stalls the matrix pipe.
-// Every wave reaches every barrier of the schedule (both roles execute exactly one barrier per kernel row of every tile).
+//     issued before the MFMAs of step s, and the hand-over to the next row sits between the last reads and the last
+//     MFMAs of the current row, so neither LDS latency nor the counter poll stalls the matrix pipe.
+// Every wait is a poll of a counter that the other role advances without waiting for the poller (a consumer at row R has
+// released R - 1, which is all the loaders need for row R + 1), bounded by a spin limit as a last resort (a wrong result, not a hang).
 #ifndef WS_ABLATE
 #define WS_ABLATE 0   // diagnostic builds only: 4 = consumers skip LDS reads + MFMA, 8 = no weight loads, 16 = no patch loads, 64 = no weight LDS writes
 #endif
 namespace ws {
 constexpr int VW = 16, TH = 16, PW = VW + 2, PH = TH + 2, NPX = PW * PH;   // 18 x 18 = 324 patch pixels
-constexpr int PIT = 6, FR = 64, PLANE = PIT * FR * PROW;                    // 36,864 B per patch plane
-constexpr int AROWB = PW * PROW;                                            // bytes between patch rows
+constexpr int PIT = 6, FR = 64, PLANE = NPX * 64;                           // 20,736 B per patch plane: dense 64-B pixel rows, the 16-B slots
+                                                                            // XOR-swizzled by the pixel's COLUMN ((px >> 1) & 3): conflict-free b128
+                                                                            // reads for every tap shift, and row shifts are plain address offsets
+constexpr int AROWB = PW * 64;                                              // bytes between patch rows
 constexpr int BN = 128, WTILE = BN * 64, WIT = 3 * WTILE / (256 * 16);      // 6 x 16 B per loader thread per kernel row
 constexpr int CBUF = BN * 4;                                                // bias + emb of one tile's channels (f32)
-constexpr int NPLANES = 2, NWBUF = 3;                                        // patch planes / weight row buffers
-constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE + 2 * CBUF;   // 148,480 B
+constexpr int NPLANES = 3, NWBUF = 4;                                        // patch planes / weight row buffers
+constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE + 2 * CBUF + 32;   // 161,568 B (+ the eight counters)
+constexpr int SPIN_LIMIT = 1 << 22;
 }  // namespace ws
 
 // GN affine (+ SiLU) of one 16-byte fragment.  bf16: fp32 math on element PAIRS (v_pk_fma/mul/add_f32: two elements per VALU
@@ -76,6 +88,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   char* pbuf = smem;                       // NPLANES patch planes
   char* wbuf = smem + NPLANES * PLANE;     // NWBUF x (3 weight tiles of one kernel row)
   char* cbuf = wbuf + NWBUF * 3 * WTILE; // 2 x accumulator start values (bias + timestep embedding) of a tile's 128 channels
+  uint32_t* c_prod = reinterpret_cast<uint32_t*>(cbuf + 2 * CBUF);   // [4]: kernel rows staged by loader wave w
+  uint32_t* c_cons = c_prod + 4;                                     // [4]: kernel rows read by consumer wave w
 
   const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -101,15 +115,72 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   int t_first = (int)blockIdx.x - (int)gridDim.x;
   t_first = next_valid(t_first);
   if (t_first >= ntp) return;        // whole workgroup leaves together: no barrier is ever reached
+  if (threadIdx.x < 8) c_prod[threadIdx.x] = 0u;
+  __syncthreads();                   // the only barrier of the kernel
+  // poll until min(cp[0..3]) >= target; the other role never waits for this wave to get there
+  // Both helpers are single asm blocks: as C++ (a spin loop, an `if (lane == 0)`) they put control flow into the consumers' row loop,
+  // and the register allocator, already at the 256-VGPR limit there, answered with 16-byte scratch spills per row.  EXEC is all
+  // ones at every call site (wave-uniform control flow only) and is restored; s_waitcnt lgkmcnt(0) also retires the wave's own
+  // outstanding fragment reads, which it would have to wait for before the next row's MFMAs anyway.
+  auto wait_ge = [&](const uint32_t* cp, uint32_t target) {
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)cp;
+    uint32_t v0, v1, v2, v3; int sv, spins = SPIN_LIMIT;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %6\n\t"
+        "ds_read_b32 %1, %6 offset:4\n\t"
+        "ds_read_b32 %2, %6 offset:8\n\t"
+        "ds_read_b32 %3, %6 offset:12\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_min_u32 %0, %0, %1\n\t"
+        "v_min_u32 %2, %2, %3\n\t"
+        "v_min_u32 %0, %0, %2\n\t"
+        "s_nop 0\n\t"
+        "v_readfirstlane_b32 %4, %0\n\t"
+        "s_cmp_ge_u32 %4, %7\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sub_u32 %5, %5, 1\n\t"
+        "s_cmp_eq_u32 %5, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n\t"
+        "2:"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&s"(sv), "+s"(spins)
+        : "v"(a), "s"(target)
+        : "scc", "memory");
+  };
+  auto bump = [&](uint32_t* cp) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cp;
+    const uint32_t one = 1u;
+    asm volatile(
+        "s_mov_b64 exec, 1\n\t"
+        "ds_add_u32 %0, %1\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "v"(a), "v"(one)
+        : "memory");
+  };
 
   if (loader) {
     // ================================= LOADER waves =================================
-    switch (p.stagger > 0 ? ((p.stagger >> 2) & 3) : 0) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
+    switch (p.stagger > 0 ? ((p.stagger >> 2) & 3) : 2) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src1 ? p.src1 : p.src0), 0, p.bytes1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wbytes, 0x00020000);
+    // patch fragment u of a thread: pixel frow + 64 u (u < 5: 320 of the 324 patch pixels, 80 per wave); the last four pixels are
+    // fragment 5 of lanes 0-15 of ONE wave, which changes with every chunk (`xw`): all four loader waves do 5.25 commits per chunk
+    // on average instead of 6 / 5 / 5 / 5 (the slowest wave sets the pace of a row)
     const int fq = tid & 3, frow = tid >> 2;
+    const bool pok5 = (lane >> 2) < 4;
     const bool pro = PRO && !(p.ablate & 2);
+    int pdst[PIT];                   // LDS offset of fragment u inside a plane (tile-independent)
+#pragma unroll
+    for (int u = 0; u < PIT; ++u) {
+      const int i = u < 5 ? frow + u * FR : 320 + (lane >> 2);
+      const int py = (int)(((float)i + 0.5f) * (1.0f / (float)PW)), px = i - py * PW;
+      pdst[u] = i * 64 + 16 * (fq ^ ((px >> 1) & 3));
+    }
+    int xw = 0;                      // the wave that commits fragment 5 of the chunk being completed
     uint32_t woff[WIT];
 #pragma unroll
     for (int i = 0; i < WIT; ++i) woff[i] = (i * 256 + tid) * 16;
@@ -123,9 +194,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       const int cy0 = y0 - 1, cx0 = x0 - 1;
 #pragma unroll
       for (int u = 0; u < PIT; ++u) {
-        const int i = frow + u * FR;
+        const int i = u < 5 ? frow + u * FR : 320 + (lane >> 2);
         int s = -1;
-        if (i < NPX) {
+        if (u < 5 || pok5) {
           const int py = (int)(((float)i + 0.5f) * (1.0f / (float)PW)), px = i - py * PW;   // exact: i < 384
           const int cy = cy0 + py, cx = cx0 + px;
           if (cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
@@ -172,12 +243,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     };
     auto commit_frag = [&](auto uc, int plane, uint32_t mask) {
       constexpr int u = decltype(uc)::value;
+      if constexpr (u == 5) { if (wave8 != xw) return; }
       u32x4 outv = raw[u];
       if (pro) {
         outv = ws_pro_frag(raw[u], pa, pb, PRO == 2, T());
         if (!((mask >> u) & 1u)) outv = u32x4{0u, 0u, 0u, 0u};   // zero padding applies AFTER the prologue
       }
-      *reinterpret_cast<u32x4*>(pbuf + plane * PLANE + (frow + u * FR) * PROW + fq * 16) = outv;
+      if (u < 5 || pok5) *reinterpret_cast<u32x4*>(pbuf + plane * PLANE + pdst[u]) = outv;
     };
 
     // ---- weight stream: one kernel row ahead, moved by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, no
@@ -210,9 +282,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(8 | (7 << 4) | (0 << 8));   // vmcnt(8) lgkmcnt(0)
     };
-    auto bare_barrier = [&]() {
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+    // Row R of the stream (all tiles): weights in buffer R % NWBUF, patch in plane (R / 3) % NPLANES.  The interval that ends by
+    // publishing row R writes patch fragments for rows >= R (planes last read by row R - 5 or earlier) and queues the DMA of row
+    // R + 1 into the buffer row R + 1 - NWBUF = R - 3 was read from: both are free once the consumers have released row R - 3.
+    int R = 0;
+    auto acquire_free = [&]() {
+      if (R >= NWBUF - 1) wait_ge(c_cons, (uint32_t)(R - (NWBUF - 2)));
     };
 
     // ---- accumulator start values of a tile: 128 channels, 4 per thread of the first half-wave ----
@@ -270,13 +345,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
           STAMP(3)
           wait_landed();
           STAMP(1)                     // (diagnostic build: slot 1 = time spent in the counted wait)
-          bare_barrier();              // kernel row (t, c, ky) and its patch are in LDS
+          bump(c_prod + wave8);        // this wave's share of kernel row (t, c, ky) and of its patch is in LDS
+          ++R;
+          acquire_free();              // before anything of the next interval is written
           STAMP(4)
         };
         // ---- ky = 0 ----
         cinit_load(t_next < ntp ? t_next : t);   // next tile's accumulator start values (tiny, L2-resident; loaded every chunk so that no load sits under a branch)
         commit_frag(IC<4>(), plane, vmask_cm); issue_frag(IC<4>());
         commit_frag(IC<5>(), plane, vmask_cm); issue_frag(IC<5>());
+        xw = (xw + 1) & 3;
         STAMP(2)
         tail();
         // ---- switch to the next chunk ----
@@ -287,7 +365,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         take_ab();
         ld_advance();                  // -> the chunk after the next one
         issue_ab();
-        plane ^= 1;
+        plane = plane == NPLANES - 1 ? 0 : plane + 1;
         // ---- ky = 1 ----
         if (nx_ok) commit_frag(IC<0>(), plane, vmask_cm);
         issue_frag(IC<0>());
@@ -312,12 +390,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   } else {
     // ================================= CONSUMER waves =================================
     // the MFMA stream goes first when both waves of a SIMD are ready (experiment knob: MI355_CONV_STAGGER = consumer | loader << 2)
-    switch (p.stagger > 0 ? (p.stagger & 3) : 2) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
+    switch (p.stagger > 0 ? (p.stagger & 3) : 1) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
     const int wave = wave8 - 4;
     const int wm = wave >> 1, wn = wave & 1;   // pixel rows 8*wm .. 8*wm+7 of the tile, channels 64*wn .. 64*wn+63
     const int lr = lane & 15, lq = lane >> 4;
-    const int a_base = (wm * 8 * PW + lr) * PROW + lq * 16;                 // + mi * AROWB (+ ky * AROWB + kx * PROW)
-    const int b_base = (wn * 64 + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));   // + ni * 1024 (+ kx * WTILE)
+    int a_cur[3];                                                           // per tap column kx (the slot swizzle follows the pixel column); + mi * AROWB
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) a_cur[kx] = (wm * 8 * PW + lr + kx) * 64 + 16 * (lq ^ (((lr + kx) >> 1) & 3));
+    int b_cur = (wn * 64 + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));          // + ni * 1024 (+ kx * WTILE)
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (p.ablate & 1) ? 0u : p.obytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.out), 0, p.rbytes, 0x00020000);
     constexpr bool PAIR = E::DTYPE == 1;
@@ -338,20 +418,26 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     };
     STAMP_DECL
     // row state of the stream of kernel rows (continuous across chunks and tiles)
-    int ky = 0, plane = 0, sel = 0, a_cur = a_base, b_cur = b_base;
+    int ky = 0, plane = 0, sel = 0;   // the fragment addresses move by wave-uniform steps (no per-lane base registers kept)
+    uint32_t rowc = 0;                // row of the stream this wave multiplies
     const bool gate512 = p.N > 0;   // always true, opaque to the compiler (WS_ABLATE & 512)
     auto advance_row = [&]() {
-      sel = sel == NWBUF - 1 ? 0 : sel + 1;
-      if (++ky == 3) { ky = 0; plane ^= 1; }
-      a_cur = a_base + plane * PLANE + ky * AROWB;
-      b_cur = b_base + sel * (3 * WTILE);
+      int bstep = 3 * WTILE, astep = AROWB;
+      if (sel == NWBUF - 1) { sel = 0; bstep = -(NWBUF - 1) * 3 * WTILE; } else ++sel;
+      if (++ky == 3) {
+        ky = 0;
+        if (plane == NPLANES - 1) { plane = 0; astep = -(NPLANES - 1) * PLANE - 2 * AROWB; } else { ++plane; astep = PLANE - 2 * AROWB; }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) a_cur[kx] += astep;
+      b_cur += bstep;
     };
     auto read_a = [&](auto bufc, auto halfc, auto kxc) {
       constexpr int buf = decltype(bufc)::value, half = decltype(halfc)::value, kx = decltype(kxc)::value;
       if constexpr (WS_ABLATE & 4) return;
       if constexpr (WS_ABLATE & 512) { if (gate512) return; }   // timing experiment: MFMAs on stale fragments, no LDS reads
 #pragma unroll
-      for (int j = 0; j < 4; ++j) af[buf][j] = *reinterpret_cast<const u32x4*>(pbuf + a_cur + (half * 4 + j) * AROWB + kx * PROW);
+      for (int j = 0; j < 4; ++j) af[buf][j] = *reinterpret_cast<const u32x4*>(pbuf + a_cur[kx] + (half * 4 + j) * AROWB);
     };
     auto read_b = [&](auto bufc, auto kxc) {
       constexpr int buf = decltype(bufc)::value, kx = decltype(kxc)::value;
@@ -373,7 +459,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       } else {
         if (more_rows) {
           STAMP(6)
-          __syncthreads();             // the next kernel row is staged; every read of this row has been issued and has landed
+          bump(c_cons + wave);         // every read of this row has been issued: LDS performs the add after them
+          wait_ge(c_prod, rowc + 2u);  // the next kernel row is staged
+          ++rowc;
           STAMP(5)
           advance_row();
           read_a(IC<0>(), IC<0>(), IC<0>());
@@ -408,7 +496,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       __builtin_amdgcn_sched_barrier(0);
     };
 
-    __syncthreads();                   // kernel row 0 of the first tile is staged
+    wait_ge(c_prod, 1u);               // kernel row 0 of the first tile is staged
     STAMP(5)
     read_a(IC<0>(), IC<0>(), IC<0>());
     read_b(IC<0>(), IC<0>());
@@ -426,8 +514,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         step(IC<0>(), IC<4>(), IC<0>(), true); step(IC<0>(), IC<5>(), IC<0>(), true);
         step(IC<1>(), IC<0>(), IC<0>(), true); step(IC<1>(), IC<1>(), IC<0>(), true);
         step(IC<1>(), IC<2>(), IC<0>(), true); step(IC<1>(), IC<3>(), IC<0>(), true);
-        step(IC<1>(), IC<4>(), IC<0>(), true); step(IC<1>(), IC<5>(), IC<0>(), !last_pair || t_next < ntp);
+        step(IC<1>(), IC<4>(), IC<0>(), true); step(IC<1>(), IC<5>(), IC<0>(), !last_pair);
       }
+      // End of a tile: the last row is released before the epilogue (the loaders keep running through it), but the first fragments
+      // of the next tile are read AFTER it - held across the epilogue they were 32 more live registers at the kernel's pressure peak
+      // (scratch spills inside the row loop); a tile start now exposes one LDS round trip per 12-48 rows instead.
+      if (t_next < ntp) bump(c_cons + wave);
       if constexpr ((WS_ABLATE & 256) != 0) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
@@ -520,6 +612,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * 2 + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * 64) >> 2)) * 2, lq, lr);
       }
       STAMP(7)
+      if (t_next < ntp) {
+        wait_ge(c_prod, rowc + 2u);
+        ++rowc;
+        advance_row();
+        read_a(IC<0>(), IC<0>(), IC<0>());
+        read_b(IC<0>(), IC<0>());
+      }
       t = t_next;
     }
     STAMP_FLUSH

@@ -18,12 +18,13 @@ struct GnKArgs {
   float* a; float* b;
   void* y; int y_silu;   // optional: also write silu?(a*x + b) as one NHWC tensor of C0 + C1 channels (small images: see gn_affine_launch)
   float* mean; float* rstd;   // optional [N][groups]
+  const void* warm; uint32_t warm_bytes;   // L2 warm-up of the consumer conv's weights by one extra wave (common.h l2_warm_wave)
 };
 
 constexpr int GN_THREADS = 512;
 
 template <typename T>
-__global__ void __launch_bounds__(GN_THREADS) gn_affine_kernel(GnKArgs p) {
+__global__ void __launch_bounds__(GN_THREADS + 64) gn_affine_kernel(GnKArgs p) {
   constexpr int V = Elem<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int C = p.C0 + p.C1, CV = C / V;
@@ -35,6 +36,7 @@ __global__ void __launch_bounds__(GN_THREADS) gn_affine_kernel(GnKArgs p) {
   float* g_mean = ch_q + C;                 // [groups]
   float* g_rstd = g_mean + p.groups;
   const int tid = threadIdx.x, n = blockIdx.x;
+  if (tid >= GN_THREADS) { l2_warm_wave(p.warm, p.warm_bytes); return; }   // the extra wave (launched only when there is something to warm)
   const int frag = tid % CV, prow = tid / CV;
   const int cb = frag * V;
   float s[V], q[V];
@@ -138,8 +140,9 @@ struct GnFinArgs {
   int HW, groups; float eps;
   const float* gamma; const float* beta; const float* film; int film_stride;
   float* a; float* b;
+  const void* warm; uint32_t warm_bytes;   // as in GnKArgs: one extra wave touches the consumer conv's weights
 };
-__global__ void __launch_bounds__(256) gn_finalize_kernel(GnFinArgs p) {
+__global__ void __launch_bounds__(320) gn_finalize_kernel(GnFinArgs p) {
   extern __shared__ __attribute__((aligned(16))) float fsm[];
   const int C = p.C0 + p.C1, Q = C >> 2, Q0 = p.C0 >> 2, Q1 = p.C1 >> 2;
   float* qs = fsm;            // [Q] sums
@@ -147,6 +150,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(GnFinArgs p) {
   float* g_mean = qq + Q;     // [groups]
   float* g_rstd = g_mean + p.groups;
   const int tid = threadIdx.x, n = blockIdx.x;
+  if (tid >= 256) { l2_warm_wave(p.warm, p.warm_bytes); return; }
   for (int q = tid; q < Q; q += 256) {
     const bool first = q < Q0;
     const float* base = first ? p.st0 + ((size_t)n * p.slots0 * Q0 + q) * 2 : p.st1 + ((size_t)n * p.slots1 * Q1 + (q - Q0)) * 2;
@@ -272,11 +276,12 @@ int gn_affine_launch(const GnDesc& d, hipStream_t stream) {
   MI355_REQUIRE(d.C0 % V == 0 && d.C1 % V == 0, -2, "groupnorm: channels must be a multiple of the 16-byte fragment");
   MI355_REQUIRE(C / V <= GN_THREADS, -4, "groupnorm: too many channels");
   MI355_REQUIRE(d.groups <= GN_THREADS, -4, "groupnorm: too many groups");
-  GnKArgs a{d.src0, d.src1, d.C0, d.C1, d.N, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b, d.y, d.y_silu, d.mean, d.rstd};
+  GnKArgs a{d.src0, d.src1, d.C0, d.C1, d.N, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b, d.y, d.y_silu, d.mean, d.rstd, d.warm, d.warm_bytes};
   const int ppi = GN_THREADS / (C / V);
   const size_t lds = ((size_t)2 * ppi * C + 2 * C + 2 * d.groups) * sizeof(float);
-  if (d.dtype == 0) hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(d.N), dim3(GN_THREADS), lds, stream, a);
-  else hipLaunchKernelGGL(gn_affine_kernel<bf16>, dim3(d.N), dim3(GN_THREADS), lds, stream, a);
+  const int nthreads = GN_THREADS + (d.warm && d.warm_bytes ? 64 : 0);
+  if (d.dtype == 0) hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(d.N), dim3(nthreads), lds, stream, a);
+  else hipLaunchKernelGGL(gn_affine_kernel<bf16>, dim3(d.N), dim3(nthreads), lds, stream, a);
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -287,9 +292,9 @@ int gn_finalize_launch(const GnFinDesc& d, hipStream_t stream) {
   MI355_REQUIRE(C % d.groups == 0 && (C / d.groups) % 4 == 0 && d.C0 % 4 == 0 && d.C1 % 4 == 0, -2,
                 "gn_finalize: groups must be whole channel quads");
   MI355_REQUIRE(d.groups <= 256, -4, "gn_finalize: too many groups");
-  GnFinArgs a{d.stats0, d.stats1, d.slots0, d.slots1, d.C0, d.C1, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b};
+  GnFinArgs a{d.stats0, d.stats1, d.slots0, d.slots1, d.C0, d.C1, d.HW, d.groups, d.eps, d.gamma, d.beta, d.film, d.film_stride, d.a, d.b, d.warm, d.warm_bytes};
   const size_t lds = ((size_t)2 * (C / 4) + 2 * d.groups) * sizeof(float);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d.N), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(d.N), dim3(d.warm && d.warm_bytes ? 320 : 256), lds, stream, a);
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }

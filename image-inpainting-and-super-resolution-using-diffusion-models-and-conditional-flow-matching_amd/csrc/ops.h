@@ -66,6 +66,7 @@ struct GnDesc {
   float* b = nullptr;
   void* y = nullptr; int y_silu = 0;   // optional: also write silu?(a*x + b), NHWC [N][HW][C0 + C1] (the consumer conv then has no prologue)
   float* mean = nullptr; float* rstd = nullptr;   // optional [N][groups]: kept for the backward pass (reconstruction guidance)
+  const void* warm = nullptr; uint32_t warm_bytes = 0;   // optional: packed weights of the conv this pass feeds (common.h l2_warm_issue)
 };
 int gn_affine_launch(const GnDesc& d, hipStream_t stream);
 // The same (a, b) from the partial sums the producing convs left (ConvDesc::gn_stats): no pass over the activation.
@@ -77,6 +78,7 @@ struct GnFinDesc {
   const float* gamma = nullptr; const float* beta = nullptr;
   const float* film = nullptr; int film_stride = 0;
   float* a = nullptr; float* b = nullptr;
+  const void* warm = nullptr; uint32_t warm_bytes = 0;   // as GnDesc::warm
 };
 int gn_finalize_launch(const GnFinDesc& d, hipStream_t stream);
 // out = avgpool2x2(silu?(a * in + b)) on NHWC tensors (a, b per (n, c), may be null): the ResBlock(down=True) input path

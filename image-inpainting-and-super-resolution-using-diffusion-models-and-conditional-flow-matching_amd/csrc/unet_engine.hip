@@ -515,6 +515,15 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   const int S = net->cfg.image_size;
   if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
   { mi355_op_profile r{}; r.kind = MI355_OP_PRELUDE; mark(r); }
+  // the conv a GroupNorm pass feeds is the next op of the plan: the pass warms the L2s with its weights (common.h l2_warm_wave)
+  static const int warm_mask = getenv("MI355_L2_WARM") ? atoi(getenv("MI355_L2_WARM")) : 1;   // 1 = statistics / apply passes, 2 = finalize passes (measured: no gain, off)
+  auto warm_next = [&](const PlanOp& op, const void*& wp, uint32_t& wb, int bit) {
+    const size_t oi = (size_t)(&op - net->ops.data());
+    if (!(warm_mask & bit) || oi + 1 >= net->ops.size() || net->ops[oi + 1].kind != OP_CONV) return;
+    const PlanOp& nx = net->ops[oi + 1];
+    const int cin = net->tensors[nx.src0].C + (nx.src1 >= 0 ? net->tensors[nx.src1].C : 0);
+    wp = W + nx.w_off; wb = (uint32_t)conv_packed_weight_bytes(dtype, nx.Cout, cin, nx.ks);
+  };
   for (const PlanOp& op : net->ops) {
     mi355_op_profile r{};
     const PlanTensor& s0 = net->tensors[op.src0];
@@ -525,6 +534,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
       if (op.film_emb_off >= 0) { g.film = embp + op.film_emb_off; g.film_stride = estride; }
       g.a = F(l.gna); g.b = F(l.gnb);
+      warm_next(op, g.warm, g.warm_bytes, 2);
       rc = gn_finalize_launch(g, stream);
       r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
       r.bytes = 0;   // no activation traffic: the statistics came with the producers' epilogues
@@ -539,6 +549,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
         g.a = sp; g.b = sp + (size_t)B * Cs; g.mean = sp + (size_t)2 * B * Cs; g.rstd = g.mean + (size_t)B * 32;
       }
       if (op.dst >= 0) { g.y = TP(op.dst); g.y_silu = op.pro_silu; }
+      warm_next(op, g.warm, g.warm_bytes, 1);
       rc = gn_affine_launch(g, stream);
       r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
       r.bytes = (double)B * s0.H * s0.W * (s0.C + C1) * esz * (op.dst >= 0 ? 2 : 1);
