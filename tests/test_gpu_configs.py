@@ -91,6 +91,8 @@ WS_CASES = [
     (64, 128, 0, 32, 256, 0, False, True, 1),      # no prologue, two channel tiles, emb + residual
     (256, 256, 0, 8, 256, 0, False, True, 1),      # 8x8 level at the bench batch: emb + residual per image
     (255, 128, 128, 8, 256, 0, True, True, 1),     # the same with per-image GN prologue, concat, odd batch
+    (64, 128, 0, 28, 256, 0, True, True, 1),       # 256-channel tiles (8 x 16 pixels) on a ragged image: partial tiles in x and y
+    (40, 64, 64, 32, 256, 0, True, False, 2),      # 256-channel tiles, concat, RES_UP2 residual
     # 8x8 / 4x4 levels without prologue => conv3x3_small_kernel (LDS-resident patch, weights straight into registers)
     (256, 256, 256, 8, 256, 0, False, True, 0),    # 512 -> 256 @ 8x8, concat: one workgroup per image, waves split N (fp32: two K phases)
     (128, 128, 128, 8, 256, 0, False, False, 1),   # fewer tiles than CUs: wave pairs split K
