@@ -291,6 +291,9 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used
     if ((size_t)nchunks * 128 * 64 + 2 * 3 * 8192 <= 80 * 1024) { BM = 128; GC = 3; }
     else if ((size_t)nchunks * 128 * 64 + 2 * 1 * 8192 <= 80 * 1024) { BM = 128; GC = 1; }
   }
+  // few pixels (8x8 / 4x4 levels) and many input channels (skip convs over a concat): with the one-chunk weight groups the stationary
+  // tile still fits (512 -> 256 at 8x8: 17.8 -> 14.2 us); with many pixels the plain kernel's 128 x 128 tiles stay faster (measured)
+  if ((M + 127) / 128 < 512 && (size_t)nchunks * 64 * 64 + 2 * 3 * 8192 > 80 * 1024 && (size_t)nchunks * 64 * 64 + 2 * 1 * 8192 <= 80 * 1024) GC = 1;
   const size_t wl = 2 * (size_t)GC * 8192;
   if ((size_t)nchunks * BM * 64 + wl > 160 * 1024) return 1;
   // A stationary tile only pays when it is reused by several output-channel tiles or when two workgroups still fit a CU
@@ -333,10 +336,12 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used
   if (d.dtype == 0) {
     if (BM == 128 && GC == 3) rc = launch1<float, 128, 3>(a, grid, lds, stream);
     else if (BM == 128) rc = launch1<float, 128, 1>(a, grid, lds, stream);
+    else if (GC == 1) rc = launch1<float, 64, 1>(a, grid, lds, stream);
     else rc = launch1<float, 64, 3>(a, grid, lds, stream);
   } else {
     if (BM == 128 && GC == 3) rc = launch1<bf16, 128, 3>(a, grid, lds, stream);
     else if (BM == 128) rc = launch1<bf16, 128, 1>(a, grid, lds, stream);
+    else if (GC == 1) rc = launch1<bf16, 64, 1>(a, grid, lds, stream);
     else rc = launch1<bf16, 64, 3>(a, grid, lds, stream);
   }
   if (rc) return rc;
