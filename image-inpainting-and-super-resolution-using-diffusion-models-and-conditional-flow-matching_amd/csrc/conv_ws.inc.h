@@ -533,8 +533,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       GnPartial<NI> gp;
       const bool do_gn = p.gn_stats != nullptr;
       const bool gn_mask = ((p.Wo | p.Ho) & 15) != 0;   // partial 16x16 tiles exist: out-of-image pixels must not count
-      auto epi_half = [&](auto hc) {
-        constexpr int h = decltype(hc)::value;
+      // HAS_RES / GNM (0 = no statistics, 1 = statistics, 2 = statistics with out-of-image pixels masked) are compile-time inside one
+      // copy of the epilogue and chosen by wave-uniform branches outside it: as run-time flags inside the loops they became selects
+      // and zero-adds (44 VALU instructions per 16-byte store instead of about 20; the epilogue is 13 % of a 12-row tile)
+      auto epi_half = [&](auto hc, auto resc, auto gnc) {
+        constexpr int h = decltype(hc)::value, GNM = decltype(gnc)::value;
+        constexpr bool HAS_RES = decltype(resc)::value != 0;
         uint32_t ovo[4], rvo[4];
         float vm[4];
 #pragma unroll
@@ -546,10 +550,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
           ovo[j] = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.obytes;
           uint32_t rpix = opix;
           if (p.res_mode == RES_UP2) rpix = (uint32_t)((n0 * p.Hr + (y >> 1)) * p.Wr + (x >> 1));
-          rvo[j] = (ok && p.res_mode != RES_NONE) ? (rpix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.rbytes;
+          rvo[j] = (ok && HAS_RES) ? (rpix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.rbytes;
         }
         u32x4 rr[4][NP2];
-        if (p.res_mode != RES_NONE) {
+        if constexpr (HAS_RES) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -563,18 +567,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               f32x4 o = acc[mi][ni];
-              if (p.res_mode != RES_NONE) {
+              if constexpr (HAS_RES) {
                 const f32x4 tt = __builtin_bit_cast(f32x4, rr[j][ni]);
                 o = f32x4{o[0] + tt[0], o[1] + tt[1], o[2] + tt[2], o[3] + tt[3]};
               }
-              if (do_gn) gp.add(ni, o[0], o[1], o[2], o[3], gn_mask, vm[j]);
+              if constexpr (GNM != 0) gp.add(ni, o[0], o[1], o[2], o[3], GNM == 2, vm[j]);
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo[j] + ni * 16 * ESZ, 0, 0);
             }
           } else {
 #pragma unroll
             for (int k = 0; k < NP2; ++k) {
               float ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
-              if (p.res_mode != RES_NONE) {   // un-swap the 8-channel residual piece back to the accumulator layout
+              if constexpr (HAS_RES) {   // un-swap the 8-channel residual piece back to the accumulator layout
                 const auto s0 = __builtin_amdgcn_permlane16_swap(rr[j][k][0], rr[j][k][2], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(rr[j][k][1], rr[j][k][3], false, false);
                 const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
@@ -588,14 +592,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
               float va[4], vb[4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                va[q] = acc[mi][2 * k][q] + ra[q];
-                vb[q] = acc[mi][2 * k + 1][q] + rb[q];
+                va[q] = HAS_RES ? acc[mi][2 * k][q] + ra[q] : acc[mi][2 * k][q];
+                vb[q] = HAS_RES ? acc[mi][2 * k + 1][q] + rb[q] : acc[mi][2 * k + 1][q];
                 ta[q] = (bf16)va[q];
                 tb[q] = (bf16)vb[q];
               }
-              if (do_gn) {
-                gp.add(2 * k, va[0], va[1], va[2], va[3], gn_mask, vm[j]);
-                gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], gn_mask, vm[j]);
+              if constexpr (GNM != 0) {
+                gp.add(2 * k, va[0], va[1], va[2], va[3], GNM == 2, vm[j]);
+                gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], GNM == 2, vm[j]);
               }
               const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
               const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
@@ -605,8 +609,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
           }
         }
       };
-      epi_half(IC<0>());
-      epi_half(IC<1>());
+      auto epi = [&](auto resc, auto gnc) { epi_half(IC<0>(), resc, gnc); epi_half(IC<1>(), resc, gnc); };
+      if (p.res_mode != RES_NONE) {
+        if (!do_gn) epi(IC<1>(), IC<0>()); else if (!gn_mask) epi(IC<1>(), IC<1>()); else epi(IC<1>(), IC<2>());
+      } else {
+        if (!do_gn) epi(IC<0>(), IC<0>()); else if (!gn_mask) epi(IC<0>(), IC<1>()); else epi(IC<0>(), IC<2>());
+      }
       if (do_gn) {   // slot = (pixel tile of the image, 8-row half); quads of this wave's 64 channels
         const int rem = mt - n0 * tpi;
         gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * 2 + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * 64) >> 2)) * 2, lq, lr);
