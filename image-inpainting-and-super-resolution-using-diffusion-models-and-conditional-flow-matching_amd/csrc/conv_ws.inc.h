@@ -149,6 +149,48 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         : "v"(a), "s"(target)
         : "scc", "memory");
   };
+  // The consumers' row hand-over, split so that the poll's LDS round trip hides behind a half-tap of MFMAs: `poll_issue` reads the
+  // four producer counters (before the MFMAs of step 4), `release_acquire` (step 5) releases the finished row and only spins if
+  // the early values were not there yet.
+  // (the early read is a C++ load, so the compiler itself waits for it before the values are used or moved)
+  auto poll_issue = [&](const uint32_t* cp, uint32_t& v0, uint32_t& v1, uint32_t& v2, uint32_t& v3) {
+    const u32x4 v = *reinterpret_cast<const volatile u32x4*>(cp);
+    v0 = v[0]; v1 = v[1]; v2 = v[2]; v3 = v[3];
+  };
+  auto release_acquire = [&](uint32_t* mine, const uint32_t* cp, uint32_t target, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    const uint32_t am = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)mine;
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)cp;
+    const uint32_t one = 1u;
+    int sv, spins = SPIN_LIMIT;
+    asm volatile(
+        "s_mov_b64 exec, 1\n\t"
+        "ds_add_u32 %7, %8\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch 3f\n\t"
+        "1:\n\t"
+        "ds_read_b32 %0, %6\n\t"
+        "ds_read_b32 %1, %6 offset:4\n\t"
+        "ds_read_b32 %2, %6 offset:8\n\t"
+        "ds_read_b32 %3, %6 offset:12\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "3:\n\t"
+        "v_min_u32 %0, %0, %1\n\t"
+        "v_min_u32 %2, %2, %3\n\t"
+        "v_min_u32 %0, %0, %2\n\t"
+        "s_nop 0\n\t"
+        "v_readfirstlane_b32 %4, %0\n\t"
+        "s_cmp_ge_u32 %4, %9\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sub_u32 %5, %5, 1\n\t"
+        "s_cmp_eq_u32 %5, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n\t"
+        "2:"
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&s"(sv), "+s"(spins)
+        : "v"(a), "v"(am), "v"(one), "s"(target)
+        : "scc", "memory");
+  };
   auto bump = [&](uint32_t* cp) {
     const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cp;
     const uint32_t one = 1u;
@@ -419,7 +461,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     STAMP_DECL
     // row state of the stream of kernel rows (continuous across chunks and tiles)
     int ky = 0, plane = 0, sel = 0;   // the fragment addresses move by wave-uniform steps (no per-lane base registers kept)
-    uint32_t rowc = 0;                // row of the stream this wave multiplies
+    uint32_t rowc = 0;
+    uint32_t pq0 = 0, pq1 = 0, pq2 = 0, pq3 = 0;   // producer counters read one half-tap before they are needed                // row of the stream this wave multiplies
     const bool gate512 = p.N > 0;   // always true, opaque to the compiler (WS_ABLATE & 512)
     auto advance_row = [&]() {
       int bstep = 3 * WTILE, astep = AROWB;
@@ -456,11 +499,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         constexpr int s1 = s + 1, half1 = s1 & 1, kx1 = s1 >> 1;
         read_a(IC<half1>(), IC<half1>(), IC<kx1>());
         if constexpr (half1 == 0) read_b(IC<(R + kx1) & 1>(), IC<kx1>());
+        if constexpr (s == 4) poll_issue(c_prod, pq0, pq1, pq2, pq3);
       } else {
         if (more_rows) {
           STAMP(6)
-          bump(c_cons + wave);         // every read of this row has been issued: LDS performs the add after them
-          wait_ge(c_prod, rowc + 2u);  // the next kernel row is staged
+          // every read of this row has been issued (LDS performs the add after them); the next kernel row is staged
+          release_acquire(c_cons + wave, c_prod, rowc + 2u, pq0, pq1, pq2, pq3);
           ++rowc;
           STAMP(5)
           advance_row();
