@@ -95,6 +95,7 @@ WS_CASES = [
     (40, 64, 64, 32, 256, 0, True, False, 2),      # 256-channel tiles, concat, RES_UP2 residual
     # 8x8 / 4x4 levels without prologue => conv3x3_small_kernel (LDS-resident patch, weights straight into registers)
     (256, 256, 256, 8, 256, 0, False, True, 0),    # 512 -> 256 @ 8x8, concat: one workgroup per image, waves split N (fp32: two K phases)
+    (255, 256, 0, 8, 256, 0, False, True, 1),      # two images per workgroup, odd batch (the last tile holds one image)
     (128, 128, 128, 8, 256, 0, False, False, 1),   # fewer tiles than CUs: wave pairs split K
     (64, 256, 0, 8, 256, 0, False, True, 1),       # all four waves split K
     (3, 256, 0, 8, 128, 0, False, True, 1),        # tiny batch
