@@ -8,7 +8,11 @@ quantise and (N > 1) the single RCCL all-gather of the shards.  Inputs (x0, cond
 before the timed region.  Weak scaling: every rank samples its own batch.
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME] [--precision bf16|fp32]
-    (N > 1: launched under torch.distributed.run)
+    N > 1: either launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or plain
+    `python bench.py --gpus N ...`: the parent then starts N fresh children of itself, one per GPU, with that environment (it has
+    not touched the GPU at that point), relays rank 0's JSON line and exits with the worst child's code.
+    --dry-run: stop before the first GPU call; every rank joins a gloo group, checks its environment and its batch shard, rank 0
+    prints one JSON line (the launcher's CPU test, tests/test_host_logic.py).
 
 Other workloads (--workload; the parity tests of the same configurations are tests/test_gpu_configs.py):
     cifar10_inpaint_ddpm50_b512        BASELINE cfg 3: CIFAR U-Net in=6, centred 16x16 = -2, Amortized DDPM Ns=50, device Philox
@@ -113,6 +117,59 @@ def make_condition(kind, B, C, S, dev, seed):
     return cond.to(dev).contiguous()
 
 
+def self_launch(n, port=0):
+    """`python bench.py --gpus N` without a launcher: start N children of this script, one per GPU, with the environment
+    torch.distributed.run would give them (rendezvous on 127.0.0.1), relay what they print, return the worst exit code.
+    The parent never initialises the GPU: it only spawns and waits (children are fresh interpreters, not forks or execs)."""
+    import socket
+    import subprocess
+
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    worst = max(rcs, key=lambda c: (c != 0, abs(c)))
+    if worst:
+        sys.stderr.write(f"bench.py: child exit codes {rcs}\n")
+    return worst
+
+
+def dry_run(a, mdist):
+    """The N > 1 path up to the first GPU call: environment, process group (gloo), this rank's shard of the global batch."""
+    rank, world, local = mdist.init_from_env(backend="gloo")
+    ok = world == a.gpus and 0 <= rank < world and local == rank
+    B = (a.batch or WORKLOADS[a.workload]["batch"])
+    lo, hi = mdist.shard_range(B * world, rank, world)   # weak scaling: B images per rank of a global batch B * world
+    ok = ok and (hi - lo) == B and lo == rank * B
+    if world > 1:
+        t = torch.tensor([rank, lo, hi], dtype=torch.int64)
+        g = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        torch.distributed.all_gather(g, t)
+        shards = [[int(v) for v in x] for x in g]
+        flag = torch.tensor([0 if ok else 1])
+        torch.distributed.all_reduce(flag)
+        ok = int(flag.item()) == 0 and [s[0] for s in shards] == list(range(world)) and all(s[1] == k * B for k, s in enumerate(shards))
+        mdist.barrier()
+    else:
+        shards = [[rank, lo, hi]]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "ok": bool(ok), "n_gpus": world, "shards": shards, "master": os.environ.get("MASTER_ADDR"),
+                          "workload": a.workload}))
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,17 +181,25 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-out", default="", help="write the per-op HIP-event profile of one forward to this JSON file")
+    ap.add_argument("--dry-run", action="store_true", help="launcher check: process group + shard ranges over gloo, no GPU call")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (default: a free one)")
     a = ap.parse_args()
 
-    from mi355 import _lib
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus, a.master_port))   # nothing above has touched the GPU (no HIP call, no library load)
+
     from mi355 import dist as mdist
+
+    if a.dry_run:
+        raise SystemExit(dry_run(a, mdist))
+
+    from mi355 import _lib
     from mi355.ops import default_ops
     from mi355.synth import synth_state_dict
 
     rank, world, local = mdist.init_from_env()
     if world != a.gpus:
-        if a.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -74,7 +74,7 @@ int mi355_unet_forward(mi355_unet* net, const float* x, int x_channels, const fl
 int mi355_unet_vjp(mi355_unet* net, const float* grad_out, float* grad_x, int x_channels, int batch, void* workspace, int64_t workspace_bytes,
                    void* stream) {
   MI355_REQUIRE(net && workspace, -1, "unet_vjp: null argument");
-  // the sampler scratch (t, eps / v, none) sits in front of the engine workspace, exactly as in the forward entry points
+  // same layout as mi355_unet_forward: the engine workspace starts at `workspace` (only the sampler loops carve their scratch in front)
   const int64_t engine_bytes = unet_workspace_bytes(net, batch);
   MI355_REQUIRE(workspace_bytes >= engine_bytes, -2, "unet_vjp: workspace too small");
   return unet_backward(net, grad_out, grad_x, x_channels, batch, workspace, workspace_bytes, S(stream));

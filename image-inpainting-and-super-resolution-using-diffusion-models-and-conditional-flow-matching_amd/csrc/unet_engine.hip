@@ -207,6 +207,10 @@ struct Walker {
       for (int v : {32, 64, 96, 128, 192, 256, 384, 512}) ok = ok || ch == v;
       if (!ok) { err = "attention: head channels must be one of 32, 64, 96, 128, 192, 256, 384, 512 (got " + std::to_string(ch) + ")"; return -1; }
     }
+    if (cfg.differentiable && ch > 256) {   // attention_bwd.hip instantiates head sizes up to 256: fail at build, not in the middle of a guidance loop
+      err = "attention: differentiable plans support head channels up to 256 (got " + std::to_string(ch) + ")";
+      return -1;
+    }
     const int yn = add_gn(x, -1, p + ".norm.weight", p + ".norm.bias", -1, 0);
     const double Tn_ = (double)T(x).H * T(x).W;
     if (yn < 0 && !cfg.differentiable && attn_fused_eligible(dtype, T(x).H * T(x).W, C, heads, ch)) {

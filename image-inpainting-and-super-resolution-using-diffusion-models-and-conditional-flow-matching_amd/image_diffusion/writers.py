@@ -47,9 +47,11 @@ class LocalWriter:
         row = {"step": step}
         row.update(scalars)
         self._pending.append(row)
-        self._count += 1
-        if self._count % self._flush_every_n == 0:
+        # the reference's order (writers.py:309-313): test (count + 1) % n first, then count the call; flush() resets the count, so the
+        # first flush comes after n calls and every later one after n - 1 (the index column of metrics.csv shows that cadence)
+        if (self._count + 1) % self._flush_every_n == 0:
             self.flush()
+        self._count += 1
 
     def flush(self):
         if not self._pending:

@@ -58,6 +58,7 @@ class UNetEngine:
                                            self._stream(), C.byref(handle)), "mi355_unet_create")
         self.handle = handle
         self._ws: Optional[torch.Tensor] = None
+        self._fwd_state = None   # (batch, workspace pointer) of the last forward(): what vjp() differentiates
         self.in_channels = self.cfg.in_channels
         self.out_channels = self.cfg.out_channels
         self.image_size = self.cfg.image_size
@@ -110,6 +111,7 @@ class UNetEngine:
         check(self.L.mi355_unet_forward(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
                                         Cc, self._chk(t, "timesteps"), self._chk(out, "out"), B, ws, wsb, self._stream()),
               "mi355_unet_forward")
+        self._fwd_state = (B, self._ws.data_ptr())
         return out
 
     def vjp(self, grad_out: torch.Tensor, x_channels: Optional[int] = None, out: Optional[torch.Tensor] = None):
@@ -124,6 +126,10 @@ class UNetEngine:
         if out is None:
             out = torch.empty(B, Cx, self.image_size, self.image_size, device=self.device, dtype=torch.float32)
         ws, wsb = self.workspace(B)
+        if self._fwd_state != (B, self._ws.data_ptr()):
+            # the arena offsets scale with the batch and the samplers / profile() reuse the workspace: anything but a forward() of
+            # this batch as the last call leaves other activations there, and the gradient would be garbage with rc 0
+            raise MI355BackendError("vjp: the last call on this engine was not forward() with the same batch (no activations to differentiate)")
         check(self.L.mi355_unet_vjp(self.handle, self._chk(grad_out, "grad_out"), self._chk(out, "grad_x"), Cx, B, ws, wsb, self._stream()),
               "mi355_unet_vjp")
         return out
@@ -155,6 +161,7 @@ class UNetEngine:
         """One forward with HIP events around every op -> list of dicts (kind, ks, cin, cout, h, w, tile, ms, flops, bytes)."""
         B, Cx, Cc = self._split(x, cond)
         out = torch.empty(B, self.out_channels, self.image_size, self.image_size, device=self.device, dtype=torch.float32)
+        self._fwd_state = None
         ws, wsb = self.workspace(B)
         cap = 4096
         recs = (_lib.OpProfileC * cap)()
@@ -181,6 +188,7 @@ class UNetEngine:
         arr = (C.c_float * len(ts))(*ts)
         traj = torch.empty((len(ts),) + tuple(x.shape), device=self.device, dtype=torch.float32) if keep_traj else None
         u8 = torch.empty(x.shape, device=self.device, dtype=torch.uint8) if want_u8 else None
+        self._fwd_state = None
         ws, wsb = self.workspace(B)
         check(self.L.mi355_cfm_euler_sample(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
                                             Cc, int(bool(cond_drift)), arr, len(ts), self._chk(traj, "traj") if traj is not None else None,
@@ -214,6 +222,7 @@ class UNetEngine:
             if noise.shape[1:] != x.shape:
                 raise ValueError("injected noise must be [n_draws, B, C, H, W]")
             ndraws = noise.shape[0]
+        self._fwd_state = None
         ws, wsb = self.workspace(B)
         check(self.L.mi355_ddpm_sample(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
                                        C.byref(tb), C.byref(opt), self._chk(noise, "noise") if noise is not None else None, ndraws, B,

@@ -35,6 +35,17 @@ def generate_samples(model, parallel, savedir, step, net_="normal"):
     model.train()
 
 
+def _invalidate_engines(target):
+    """Drop the packed-weight engine of `target` and of every sub-module that has one: the reference wraps the EMA model in
+    nn.DataParallel under --parallel (cifar10/train_cifar10.py:112-113), whose wrapper has no engine of its own - the U-Net sits
+    at `.module` - and `generate_samples(ema_model, True, ...)` samples exactly that inner module."""
+    seen = set()
+    for m in ([target] + list(target.modules() if hasattr(target, "modules") else [])):
+        if id(m) not in seen and hasattr(m, "invalidate_engine"):
+            seen.add(id(m))
+            m.invalidate_engine()
+
+
 def ema(source, target, decay):
     """cifar10/utils_cifar.py:47-53.  Device-resident fp32 tensors are updated in place by the fused HIP kernel (one launch per
     state-dict entry instead of three eager kernels + a copy); anything else (CPU tensors, integer buffers) keeps the reference's
@@ -50,8 +61,7 @@ def ema(source, target, decay):
     # neither path bumps the parameters' autograd version counters, which the packed-weight cache of UNetModel.engine() keys on:
     # without this, `ema(net, ema_model, d); generate_samples(ema_model, ...)` (cifar10/train_cifar10.py:154-159) would sample
     # from the weights packed at the first engine build
-    if hasattr(target, "invalidate_engine"):
-        target.invalidate_engine()
+    _invalidate_engines(target)
 
 
 def infiniteloop(dataloader):

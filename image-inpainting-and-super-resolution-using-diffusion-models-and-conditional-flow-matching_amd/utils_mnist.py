@@ -68,6 +68,17 @@ def generate_samples(model, parallel, savedir, step, net_="normal", solver="dopr
     model.train()
 
 
+def _invalidate_engines(target):
+    """Drop the packed-weight engine of `target` and of every sub-module that has one: the reference wraps the EMA model in
+    nn.DataParallel under --parallel (cifar10/train_cifar10.py:112-113), whose wrapper has no engine of its own - the U-Net sits
+    at `.module` - and `generate_samples(ema_model, True, ...)` samples exactly that inner module."""
+    seen = set()
+    for m in ([target] + list(target.modules() if hasattr(target, "modules") else [])):
+        if id(m) not in seen and hasattr(m, "invalidate_engine"):
+            seen.add(id(m))
+            m.invalidate_engine()
+
+
 def ema(source, target, decay):
     """utils_mnist.py:76-82.  `.data.copy_` does not bump the autograd version counters the packed-weight cache keys on,
     so the target's engine is invalidated explicitly."""
@@ -75,8 +86,7 @@ def ema(source, target, decay):
     target_dict = target.state_dict()
     for key in source_dict.keys():
         target_dict[key].data.copy_(target_dict[key].data * decay + source_dict[key].data * (1 - decay))
-    if hasattr(target, "invalidate_engine"):
-        target.invalidate_engine()
+    _invalidate_engines(target)
 
 
 def infiniteloop(dataloader):

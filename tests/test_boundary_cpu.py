@@ -256,6 +256,16 @@ def test_local_writer_files(tmp_path):
     df = pd.read_csv(tmp_path / "run" / "metrics.csv", index_col=0)
     assert df["step"].tolist() == [0, 1, 2] and df.index.tolist() == [0, 1, 0]
     assert np.isnan(df["test_conditional_mse"].iloc[0]) and df["test_conditional_mse"].iloc[2] == 0.3
+    # flush cadence of the reference (writers.py:309-313, 354-365): (count + 1) % n is tested before the call is counted and flush()
+    # resets the count, so with n = 3 the file is rewritten after calls 3, 5, 7, ... and the index column restarts there
+    w3 = LocalWriter(str(tmp_path / "run3"), flush_every_n=3)
+    sizes = []
+    for k in range(7):
+        w3.write_scalars(k, {"v": float(k)})
+        p3 = tmp_path / "run3" / "metrics.csv"
+        sizes.append(len(pd.read_csv(p3, index_col=0)) if p3.exists() else 0)
+    assert sizes == [0, 0, 3, 3, 5, 5, 7]
+    assert pd.read_csv(tmp_path / "run3" / "metrics.csv", index_col=0).index.tolist() == [0, 1, 2, 0, 1, 0, 1]
     w.write_images(7, {"samples": torch.rand(6, 1, 8, 8), "one": (torch.rand(3, 5, 4) * 255).to(torch.uint8)})
     g = Image.open(tmp_path / "run" / "images" / "samples_7.png")
     assert g.size == (6 * 10 + 2, 10 + 2)                              # make_grid: nrow 8, padding 2
@@ -353,3 +363,25 @@ def test_dopri5_error_norm_allreduce_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_ema_invalidates_engine_behind_dataparallel():
+    """cifar10/train_cifar10.py:112-113,154-159: under --parallel the EMA model is an nn.DataParallel whose U-Net sits at `.module`;
+    ema() must drop THAT module's packed-weight engine, or generate_samples(ema_model, True, ...) samples stale weights."""
+    import utils_cifar
+    import utils_mnist
+    from torchcfm_compat import UNetModelWrapper
+
+    def mk():
+        return UNetModelWrapper(dim=(1, 16, 16), num_res_blocks=1, num_channels=32, channel_mult=(1, 2), num_heads=1, num_head_channels=-1,
+                                attention_resolutions="8", dropout=0.0)
+
+    for mod in (utils_cifar, utils_mnist):
+        src, tgt = mk(), mk()
+        wrapped = torch.nn.DataParallel(tgt)
+        calls = []
+        tgt.invalidate_engine = lambda calls=calls: calls.append(1)
+        mod.ema(torch.nn.DataParallel(src), wrapped, 0.5)   # both are wrapped in the reference: the "module." keys line up
+        assert calls == [1], mod.__name__
+        mod.ema(src, tgt, 0.5)           # the bare module still works, once per call
+        assert calls == [1, 1]

@@ -1,6 +1,7 @@
 """CPU: host-side logic of the product (no GPU, no oracle in the product path): DDPM tables, likelihoods,
 state-dict layout, sampler call order with a recording op double, batch sharding / gather over gloo."""
 import math
+import json
 import os
 import re
 import subprocess
@@ -203,6 +204,24 @@ def test_all_gather_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus 2` with no launcher environment (the driver's command shape): the parent starts two ranks of itself,
+    both reach the process group (gloo here) and agree on the shard ranges; rank 0's JSON line is relayed, the exit code is the worst
+    child's.  --dry-run stops before the first GPU call."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["dry_run"] and rec["ok"] and rec["n_gpus"] == 2 and rec["master"] == "127.0.0.1"
+    assert rec["shards"] == [[0, 0, 256], [1, 256, 512]]
+    # a mismatching launcher environment is an error, not a silent single-GPU run
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
 
 
 def test_product_never_imports_oracle():
