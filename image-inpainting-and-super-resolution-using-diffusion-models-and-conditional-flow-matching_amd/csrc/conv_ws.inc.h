@@ -116,6 +116,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   t_first = next_valid(t_first);
   if (t_first >= ntp) return;        // whole workgroup leaves together: no barrier is ever reached
   if (threadIdx.x < 8) c_prod[threadIdx.x] = 0u;
+  if constexpr ((WS_ABLATE & 2048) != 0) {   // consumers-alone experiment: random bf16 operands in [0.5, 1) of either sign (zeros would raise the clock)
+    for (int i = threadIdx.x; i < (NPLANES * PLANE + NWBUF * 3 * WTILE) / 16; i += 512) {
+      uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
+      u32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; v[k] = (h & 0x807f807fu) | 0x3f003f00u; }
+      *reinterpret_cast<u32x4*>(smem + (size_t)i * 16) = v;
+    }
+  }
   __syncthreads();                   // the only barrier of the kernel
   // poll until min(cp[0..3]) >= target; the other role never waits for this wave to get there
   // Both helpers are single asm blocks: as C++ (a spin loop, an `if (lane == 0)`) they put control flow into the consumers' row loop,
@@ -153,8 +162,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   // four producer counters (before the MFMAs of step 4), `release_acquire` (step 5) releases the finished row and only spins if
   // the early values were not there yet.
   // (the early read is a C++ load, so the compiler itself waits for it before the values are used or moved)
+  // (an LDS-address-space pointer: through a generic `volatile` pointer this compiled to flat_load_dwordx4 sc0 sc1 followed by
+  //  s_waitcnt vmcnt(0) lgkmcnt(0) in front of the step's MFMAs - address-space inference skips volatile accesses, and a flat
+  //  load returns out of order with LDS reads - i.e. the "early" poll drained the fragment pipeline once per kernel row)
   auto poll_issue = [&](const uint32_t* cp, uint32_t& v0, uint32_t& v1, uint32_t& v2, uint32_t& v3) {
-    const u32x4 v = *reinterpret_cast<const volatile u32x4*>(cp);
+    const u32x4 v = *reinterpret_cast<const volatile __attribute__((address_space(3))) u32x4*>((const __attribute__((address_space(3))) uint32_t*)cp);
     v0 = v[0]; v1 = v[1]; v2 = v[2]; v3 = v[3];
   };
   auto release_acquire = [&](uint32_t* mine, const uint32_t* cp, uint32_t target, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
@@ -205,10 +217,164 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
 
   if (loader) {
     // ================================= LOADER waves =================================
+    if constexpr ((WS_ABLATE & 2048) != 0) return;   // timing experiment: consumers alone (no staging, no hand-over; they multiply whatever LDS holds)
     switch (p.stagger > 0 ? ((p.stagger >> 2) & 3) : 2) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src1 ? p.src1 : p.src0), 0, p.bytes1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wbytes, 0x00020000);
+    if constexpr (PRO == 0 && !(WS_ABLATE & 1024)) {
+    // ---------------- prologue-free input: the loaders issue DMA and counter updates only (round 3) ----------------
+    // Round-2 finding: whatever a loader wave issues is paid for by the MFMA stream of the consumer wave on its SIMD (same-box A/B in
+    // profiles/r3_experiments.md: removing a stall from the consumers alone slowed the loaders by as much).  Without a prologue nothing
+    // has to pass through registers: the patch goes global -> LDS by DMA like the weights.  A plane is 324 dense 64-byte pixel rows
+    // = 21 pieces of 1 KB (16 pixels; piece 20 = pixels 308-323, re-writing 12 pixels of piece 19 with the same bytes: no partial
+    // piece, no padding).  Lane l of a piece lands at piece base + 16 l = slot l & 3 of pixel (l >> 2), so the slot swizzle goes
+    // into the per-lane SOURCE address (fragment (l & 3) ^ ((px >> 1) & 3) of that pixel), zero padding = an out-of-range offset
+    // (the DMA then writes zeros: tools/probe/lds_dma_oob_probe.cpp).  Chunk c + 1's 21 pieces are issued during chunk c's three
+    // intervals: interval ky moves pieces 7 ky .. 7 ky + 6, wave w taking 7 ky + w and (w < 3) 7 ky + 4 + w, in front of the six
+    // weight pieces of the next kernel row; the counted wait at the end of an interval leaves exactly that interval's own pieces
+    // in flight, so everything a published row needs (its weights and ALL pieces of its chunk) was issued at least one interval ago.
+    constexpr int NPU = 6;                       // pieces per wave and chunk: u = 2 ky + h
+    const bool has_h1 = wave8 < 3;
+    uint32_t pvo0[NPU], pvo1[NPU];               // per-lane source offsets of piece u in source 0 / 1 (tile-dependent)
+    auto piece_first_pixel = [&](int u) { const int j = 7 * (u >> 1) + 4 * (u & 1) + wave8; return j == 20 ? NPX - 16 : 16 * j; };
+    auto setup = [&](int mt) {
+      int n0, y0, x0;
+      origin(mt, n0, y0, x0);
+      const int cy0 = y0 - 1, cx0 = x0 - 1;
+#pragma unroll
+      for (int u = 0; u < NPU; ++u) {
+        const int i = piece_first_pixel(u) + (lane >> 2);
+        const int py = (int)(((float)i + 0.5f) * (1.0f / (float)PW)), px = i - py * PW;   // exact: i < 384
+        const int fqx = (lane & 3) ^ ((px >> 1) & 3);
+        const int cy = cy0 + py, cx = cx0 + px;
+        int sp = -1;
+        if (cy >= 0 && cy < p.Hc && cx >= 0 && cx < p.Wc) {
+          if (p.mode == CONV_UP2) sp = (n0 * p.Hs + (cy >> 1)) * p.Ws + (cx >> 1);
+          else sp = (n0 * p.Hs + cy) * p.Ws + cx;
+        }
+        pvo0[u] = sp >= 0 ? (uint32_t)sp * (uint32_t)(p.C0 * ESZ) + fqx * 16 : p.bytes0;
+        pvo1[u] = sp >= 0 ? (uint32_t)sp * (uint32_t)(p.C1 * ESZ) + fqx * 16 : p.bytes1;
+      }
+    };
+    uint32_t woff[WIT];
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) woff[i] = (i * 256 + tid) * 16;
+    // patch stream: the chunk whose pieces are being issued (one chunk ahead of the row stream)
+    int pt_t = t_first, pt_c = 0, pt_plane = 0;
+    { int mt, nt; decode(pt_t, mt, nt); setup(mt); }
+    auto pt_advance = [&]() {
+      pt_plane = pt_plane == NPLANES - 1 ? 0 : pt_plane + 1;
+      if (++pt_c == p.nchunks) {
+        pt_c = 0;
+        pt_t = next_valid(pt_t);
+        if (pt_t < ntp) { int mt, nt; decode(pt_t, mt, nt); setup(mt); }
+      }
+    };
+    // this wave's pieces of slot ky for the patch stream's chunk -> number issued (wave-uniform)
+    auto issue_pieces = [&](auto kyc) -> int {
+      constexpr int ky = decltype(kyc)::value;
+      if (pt_t >= ntp) return 0;
+      if constexpr (WS_ABLATE & 16) return 0;
+      const int cb = pt_c * CHUNK;
+      const bool first = cb < p.C0;
+      const uint32_t so = (uint32_t)((first ? cb : cb - p.C0) * ESZ);
+      char* pl = pbuf + pt_plane * PLANE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (__attribute__((address_space(3))) void*)(pl + piece_first_pixel(2 * ky) * 64), 16,
+                                               first ? pvo0[2 * ky] : pvo1[2 * ky], so, 0, 0);
+      if (!has_h1) return 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (__attribute__((address_space(3))) void*)(pl + piece_first_pixel(2 * ky + 1) * 64), 16,
+                                               first ? pvo0[2 * ky + 1] : pvo1[2 * ky + 1], so, 0, 0);
+      return 2;
+    };
+    int wl_t = t_first, wl_row = 0, wl_nt, wl_buf = 0;
+    { int mt; decode(wl_t, mt, wl_nt); }
+    auto dma_w = [&]() {               // next row of the weight stream -> wbuf[wl_buf] (6 pieces per wave)
+      const uint32_t so = ((uint32_t)wl_nt * p.nchunks * 9 + (uint32_t)wl_row * 3) * WTILE;
+      if constexpr (!(WS_ABLATE & 8)) {
+        char* dst = wbuf + wl_buf * (3 * WTILE) + wave8 * 1024;
+#pragma unroll
+        for (int i = 0; i < WIT; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, woff[i], so, 0, 0);
+      }
+      wl_buf = wl_buf == NWBUF - 1 ? 0 : wl_buf + 1;
+      if (++wl_row == ngr) {
+        wl_row = 0;
+        wl_t = next_valid(wl_t);
+        if (wl_t < ntp) { int mt; decode(wl_t, mt, wl_nt); }
+      }
+    };
+    // all but this interval's own DMA pieces (6 weight pieces + k patch pieces) have landed; lgkmcnt(0): this wave's cbuf write
+    auto wait_landed = [&](int k) {
+      asm volatile("" ::: "memory");
+      constexpr int WK = (WS_ABLATE & 8) ? 0 : WIT;
+      if (k == 2) __builtin_amdgcn_s_waitcnt((WK + 2) | (7 << 4) | (0 << 8));
+      else if (k == 1) __builtin_amdgcn_s_waitcnt((WK + 1) | (7 << 4) | (0 << 8));
+      else __builtin_amdgcn_s_waitcnt(WK | (7 << 4) | (0 << 8));
+    };
+    int R = 0;
+    auto acquire_free = [&]() {
+      if (R >= NWBUF - 1) wait_ge(c_cons, (uint32_t)(R - (NWBUF - 2)));
+    };
+    // accumulator start values (bias + timestep embedding) of a tile's 128 channels, staged in LDS for the consumers: loaded at the
+    // start of a tile's LAST chunk, committed at its end (the compiler's wait for the two loads then finds them long complete)
+    f32x4 cv_b = f32x4{0.f, 0.f, 0.f, 0.f}, cv_e = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cst_par = 0;
+    auto cinit_load = [&](int t) {
+      int mt, nt, n0, y0, x0;
+      decode(t, mt, nt);
+      origin(mt, n0, y0, x0);
+      const int co = min(nt * BN + (tid & 31) * 4, p.Cout - 4);
+      const float* dummy = reinterpret_cast<const float*>(p.w);
+      cv_b = *reinterpret_cast<const f32x4*>(p.bias ? p.bias + co : dummy);
+      cv_e = *reinterpret_cast<const f32x4*>(p.emb ? p.emb + (size_t)n0 * p.emb_stride + co : dummy);
+    };
+    auto cinit_commit = [&]() {
+      if (tid < 32) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (p.bias ? cv_b[j] : 0.0f) + (p.emb ? cv_e[j] : 0.0f);
+        *reinterpret_cast<f32x4*>(cbuf + cst_par * CBUF + tid * 16) = v;
+      }
+      cst_par ^= 1;
+    };
+    STAMP_DECL
+    // ---- fill: accumulator start values of the first tile, all pieces of its chunk 0, weight row 0 ----
+    cinit_load(t_first);
+    cinit_commit();
+    (void)issue_pieces(IC<0>()); (void)issue_pieces(IC<1>()); (void)issue_pieces(IC<2>());
+    pt_advance();
+    dma_w();                           // row 0
+    STAMP(0)
+    for (int t = t_first; t < ntp;) {
+      const int t_next = next_valid(t);
+      for (int c = 0; c < p.nchunks; ++c) {
+        const bool last_c = c + 1 == p.nchunks && t_next < ntp;
+        auto tail = [&](int k) {
+          dma_w();
+          STAMP(3)
+          wait_landed(k);
+          STAMP(1)
+          bump(c_prod + wave8);        // this wave's share of kernel row (t, c, ky), and of every piece issued before this interval, is in LDS
+          ++R;
+          acquire_free();              // before anything of the next interval is issued
+          STAMP(4)
+        };
+        if (last_c) cinit_load(t_next);
+        const int k0 = issue_pieces(IC<0>());
+        tail(k0);
+        const int k1 = issue_pieces(IC<1>());
+        tail(k1);
+        const int k2 = issue_pieces(IC<2>());
+        pt_advance();
+        if (last_c) cinit_commit();
+        tail(k2);
+      }
+      t = t_next;
+    }
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // no DMA piece may still be in flight towards LDS when the workgroup retires
+    STAMP_FLUSH
+    } else {
     // patch fragment u of a thread: pixel frow + 64 u (u < 5: 320 of the 324 patch pixels, 80 per wave); the last four pixels are
     // fragment 5 of lanes 0-15 of ONE wave, which changes with every chunk (`xw`): all four loader waves do 5.25 commits per chunk
     // on average instead of 6 / 5 / 5 / 5 (the slowest wave sets the pace of a row)
@@ -429,6 +595,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     }
     __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));   // no DMA piece may still be in flight towards LDS when the workgroup retires
     STAMP_FLUSH
+    }   // register-staged loaders (the prologue variants)
   } else {
     // ================================= CONSUMER waves =================================
     // the MFMA stream goes first when both waves of a SIMD are ready (experiment knob: MI355_CONV_STAGGER = consumer | loader << 2)
@@ -499,12 +666,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         constexpr int s1 = s + 1, half1 = s1 & 1, kx1 = s1 >> 1;
         read_a(IC<half1>(), IC<half1>(), IC<kx1>());
         if constexpr (half1 == 0) read_b(IC<(R + kx1) & 1>(), IC<kx1>());
-        if constexpr (s == 4) poll_issue(c_prod, pq0, pq1, pq2, pq3);
+        if constexpr (s == 4 && !(WS_ABLATE & 2048)) poll_issue(c_prod, pq0, pq1, pq2, pq3);
       } else {
         if (more_rows) {
           STAMP(6)
           // every read of this row has been issued (LDS performs the add after them); the next kernel row is staged
-          release_acquire(c_cons + wave, c_prod, rowc + 2u, pq0, pq1, pq2, pq3);
+          if constexpr (!(WS_ABLATE & 2048)) release_acquire(c_cons + wave, c_prod, rowc + 2u, pq0, pq1, pq2, pq3);
           ++rowc;
           STAMP(5)
           advance_row();
@@ -540,7 +707,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       __builtin_amdgcn_sched_barrier(0);
     };
 
-    wait_ge(c_prod, 1u);               // kernel row 0 of the first tile is staged
+    if constexpr (!(WS_ABLATE & 2048)) wait_ge(c_prod, 1u);               // kernel row 0 of the first tile is staged
     STAMP(5)
     read_a(IC<0>(), IC<0>(), IC<0>());
     read_b(IC<0>(), IC<0>());
@@ -665,7 +832,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       }
       STAMP(7)
       if (t_next < ntp) {
-        wait_ge(c_prod, rowc + 2u);
+        if constexpr (!(WS_ABLATE & 2048)) wait_ge(c_prod, rowc + 2u);
         ++rowc;
         advance_row();
         read_a(IC<0>(), IC<0>(), IC<0>());

@@ -93,6 +93,12 @@ WS_CASES = [
     (255, 128, 128, 8, 256, 0, True, True, 1),     # the same with per-image GN prologue, concat, odd batch
     (64, 128, 0, 28, 256, 0, True, True, 1),       # 256-channel tiles (8 x 16 pixels) on a ragged image: partial tiles in x and y
     (40, 64, 64, 32, 256, 0, True, False, 2),      # 256-channel tiles, concat, RES_UP2 residual
+    # no prologue on the persistent kernel => its DMA-only loaders (patch pieces global -> LDS, zero padding = out-of-range offsets)
+    (128, 256, 128, 16, 256, 0, False, True, 0),   # two sources (the chunk stream switches descriptors), two channel tiles
+    (64, 128, 0, 16, 128, 2, False, True, 0),      # Upsample.conv: nearest x2 gather in the pieces' source addresses
+    (64, 128, 0, 28, 128, 0, False, True, 1),      # ragged image: partial tiles in x and y, out-of-image pixels read as zeros
+    (40, 64, 64, 32, 128, 0, False, False, 2),     # concat of two 2-chunk sources, RES_UP2 residual
+    (70, 128, 0, 20, 128, 0, False, False, 0),     # 2 x 2 tiles of a 20 x 20 image: more tiles than CUs, uneven walk lengths
     # 8x8 / 4x4 levels without prologue => conv3x3_small_kernel (LDS-resident patch, weights straight into registers)
     (256, 256, 256, 8, 256, 0, False, True, 0),    # 512 -> 256 @ 8x8, concat: one workgroup per image, waves split N (fp32: two K phases)
     (255, 256, 0, 8, 256, 0, False, True, 1),      # two images per workgroup, odd batch (the last tile holds one image)
