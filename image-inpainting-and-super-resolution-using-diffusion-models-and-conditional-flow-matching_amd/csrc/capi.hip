@@ -21,6 +21,8 @@ static size_t emb_table_bytes(const mi355_unet* net) {
   return al256((size_t)EMB_TABLE_STEPS * 4) + al256((size_t)EMB_TABLE_STEPS * ((size_t)net->emb_total + 9 * (size_t)net->cfg.model_channels) * 4);
 }
 
+static UnetRun uniform_t_run();
+
 extern "C" {
 
 int mi355_version(void) { return 100; }
@@ -69,6 +71,18 @@ int64_t mi355_unet_workspace_bytes(const mi355_unet* net, int batch) {
 int mi355_unet_forward(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels, const float* t,
                        float* out, int batch, void* workspace, int64_t workspace_bytes, void* stream) {
   return unet_forward(net, x, x_channels, cond, cond_channels, t, out, batch, workspace, workspace_bytes, S(stream));
+}
+
+int mi355_unet_forward_t(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels, float t, float* out,
+                         int batch, void* workspace, int64_t workspace_bytes, void* stream) {
+  MI355_REQUIRE(net && workspace && batch > 0, -1, "unet_forward_t: bad argument");
+  const WsLayout l = unet_ws_layout(net, batch);
+  MI355_REQUIRE((int64_t)l.total <= workspace_bytes, -2, "unet_forward_t: workspace too small");
+  // the step time lives in the first word of the workspace's emb2 region until the embedding kernels have read it (they write
+  // temb -> emb1 -> emb2 in that order, t is read by the first one only); every image shares it: ONE embedding row
+  float* tdev = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + l.emb2);
+  if (int rc = fill_launch(tdev, t, 1, S(stream))) return rc;
+  return unet_forward(net, x, x_channels, cond, cond_channels, tdev, out, batch, workspace, workspace_bytes, S(stream), uniform_t_run());
 }
 
 int mi355_unet_vjp(mi355_unet* net, const float* grad_out, float* grad_x, int x_channels, int batch, void* workspace, int64_t workspace_bytes,
@@ -333,6 +347,13 @@ int mi355_mse_per_sample(const float* a, const float* b, float* out, int batch, 
 int mi355_lincomb_per_sample(float* out, const float* x, const float* y, const float* a, const float* b, int batch,
                              int64_t elems_per_sample, void* stream) {
   return lincomb_per_sample_launch(out, x, y, a, b, batch, elems_per_sample, S(stream));
+}
+int mi355_resize_bilinear(const float* in, float* out, int64_t planes, int h_in, int w_in, int h_out, int w_out, void* stream) {
+  return resize_bilinear_launch(in, out, planes, h_in, w_in, h_out, w_out, S(stream));
+}
+int mi355_paint_patch(const float* images, const int32_t* top, const int32_t* left, int patch_size, float pad_value, int outpaint, float* out,
+                      int batch, int channels, int h, int w, void* stream) {
+  return paint_patch_launch(images, top, left, patch_size, pad_value, outpaint, out, batch, channels, h, w, S(stream));
 }
 int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream) { return quantize_u8_launch(x, out, n, S(stream)); }
 int mi355_to_unit_range(const float* x, float* out, int64_t n, void* stream) { return to_unit_range_launch(x, out, n, S(stream)); }

@@ -169,6 +169,10 @@ int quantize_u8_launch(const float* x, uint8_t* out, int64_t n, hipStream_t s);
 int to_unit_range_launch(const float* x, float* out, int64_t n, hipStream_t s);
 int randn_launch(float* out, uint64_t seed, uint64_t offset, int64_t n, hipStream_t s);
 int fill_launch(float* x, float v, int64_t n, hipStream_t s);
+// condition builders (steps.hip): bilinear resize of NCHW fp32 planes (align_corners = False), square-patch painting of a batch
+int resize_bilinear_launch(const float* in, float* out, int64_t planes, int Hi, int Wi, int Ho, int Wo, hipStream_t s);
+int paint_patch_launch(const float* img, const int* top, const int* left, int patch, float pad, int outpaint, float* out, int N, int C,
+                       int H, int W, hipStream_t s);
 int groupnorm_nchw_launch(const float* x, const float* gamma, const float* beta, float* y, int N, int C, int HW, int groups,
                           float eps, int silu, hipStream_t s);
 

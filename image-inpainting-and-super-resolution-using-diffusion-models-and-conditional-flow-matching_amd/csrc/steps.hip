@@ -271,3 +271,61 @@ int lincomb_per_sample_launch(float* out, const float* x, const float* y, const 
     st4(out, i, cnt, o);
   });
 }
+
+namespace {
+// ---- condition builders (once per batch / once per solve; AD/image_diffusion/likelihoods.py, mnist/utils_mnist_hy.py:18-28) ----------
+// Bilinear resize of NCHW fp32 planes, align_corners = False, no antialiasing: torch.nn.functional.interpolate(mode="bilinear")
+// as the reference calls it for the low-res condition (downsample_images, HyperResolution._sample, the SuperRes wrapper's
+// upsampling).  Source index = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out in fp32; the four taps are combined as
+// h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11), the operation order of ATen's kernel (no fused multiply-adds here).
+__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* in, float* out, int64_t planes, int Hi, int Wi, int Ho, int Wo,
+                                                               float sh, float sw) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= planes * Ho * Wo) return;
+  const int ox = (int)(idx % Wo);
+  const int oy = (int)((idx / Wo) % Ho);
+  const int64_t pl = idx / ((int64_t)Wo * Ho);
+  float fy = sh * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  float fx = sw * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+  const float h1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), w1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+  const float h0 = 1.f - h1, w0 = 1.f - w1;
+  const float* p = in + pl * (int64_t)Hi * Wi;
+  const float v00 = p[(int64_t)y0 * Wi + x0], v01 = p[(int64_t)y0 * Wi + x1], v10 = p[(int64_t)y1 * Wi + x0], v11 = p[(int64_t)y1 * Wi + x1];
+  out[idx] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+}
+
+// InPainting._sample / OutPainting._sample (likelihoods.py:78-87, 95-104) for a whole batch in one launch: image n's square patch
+// has its top-left corner at (top[n], left[n]) (drawn on the host in the reference's order); inside the patch the result is
+// pad_value (in-painting) or the image (out-painting), outside it the other one.
+__global__ void __launch_bounds__(256) paint_patch_kernel(const float* img, const int* top, const int* left, int patch, float pad,
+                                                           int outpaint, float* out, int64_t n_elems, int C, int H, int W) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_elems) return;
+  const int x = (int)(idx % W), y = (int)((idx / W) % H);
+  const int64_t n = idx / ((int64_t)W * H * C);
+  const int t = top[n], l = left[n];
+  const bool inside = y >= t && y < t + patch && x >= l && x < l + patch;
+  out[idx] = (inside != (outpaint != 0)) ? pad : img[idx];
+}
+
+}  // namespace
+
+int resize_bilinear_launch(const float* in, float* out, int64_t planes, int Hi, int Wi, int Ho, int Wo, hipStream_t s) {
+  MI355_REQUIRE(in && out && planes > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, -1, "resize_bilinear: bad argument");
+  const int64_t n = planes * Ho * Wo;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, planes, Hi, Wi, Ho, Wo,
+                     (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int paint_patch_launch(const float* img, const int* top, const int* left, int patch, float pad, int outpaint, float* out, int N, int C,
+                       int H, int W, hipStream_t s) {
+  MI355_REQUIRE(img && top && left && out && N > 0 && C > 0 && H > 0 && W > 0 && patch > 0, -1, "paint_patch: bad argument");
+  const int64_t n = (int64_t)N * C * H * W;
+  hipLaunchKernelGGL(paint_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, top, left, patch, pad, outpaint, out, n, C, H, W);
+  MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,8 +1,10 @@
 """Condition builders (the role of `AD/image_diffusion/likelihoods.py:12-158`): in-painting / out-painting masks with the -2
 sentinel and the bilinear down-then-up "hyper-resolution" degradation.
 
-They run once per batch, outside the per-step path, and only index / fill / resize tensors.  The reference draws one patch
-position per image in a Python loop (`Likelihood.sample`, :22-27) - reproduced, because the draw order fixes the RNG stream.
+They run once per batch, outside the per-step path.  The reference draws one patch position per image in a Python loop
+(`Likelihood.sample`, :22-27): the DRAWS are reproduced in that order (they fix the RNG stream); for device tensors the tensor work
+of the loop is one HIP launch for the whole batch (`mi355_paint_patch`), and the bilinear resizes are `mi355_resize_bilinear`
+(no ATen kernel on device data).  CPU tensors keep the reference's eager expressions (host-side logic, CPU tests).
 """
 from typing import Callable, Dict, Type
 
@@ -11,6 +13,10 @@ import torch.nn.functional as F
 
 
 def _bilinear(x, size):
+    if x.is_cuda:
+        from mi355.ops import default_ops
+
+        return default_ops.resize_bilinear(x.float().contiguous(), tuple(size))
     return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
 
 
@@ -53,6 +59,22 @@ class Painting(Likelihood):
         top, left = self.get_random_patch(images.shape[-1])
         return slice(int(top), int(top) + self.patch_size), slice(int(left), int(left) + self.patch_size)
 
+    _outpaint = False
+
+    def sample(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            return super().sample(x)
+        # device batch: the same two scalar draws per image, in batch order, then one launch for all images
+        from mi355.ops import default_ops
+
+        tops, lefts = [], []
+        for _ in range(x.shape[0]):
+            top, left = self.get_random_patch(x.shape[-1])
+            tops.append(int(top)); lefts.append(int(left))
+        t = torch.tensor(tops, dtype=torch.int32).to(x.device)
+        l = torch.tensor(lefts, dtype=torch.int32).to(x.device)
+        return default_ops.paint_patch(x.detach().float().contiguous(), t, l, self.patch_size, self.pad_value, outpaint=self._outpaint)
+
     def none_like(self, x):
         return torch.full_like(x, self.pad_value)
 
@@ -79,6 +101,8 @@ class InPainting(Painting):
 class OutPainting(Painting):
     """Only the patch of the image is known (:90-104)."""
 
+    _outpaint = True
+
     def _sample(self, images):
         ys, xs = self._window(images)
         out = self.none_like(images)
@@ -99,7 +123,12 @@ class HyperResolution(Likelihood):
 
     def _sample(self, images):
         small = _bilinear(images, (self.target_height, self.target_width))
-        return F.interpolate(small, tuple(images.shape[2:4]), mode="bilinear")
+        return _bilinear(small, tuple(images.shape[2:4]))
+
+    def sample(self, x):
+        if x.is_cuda:            # per-image resizes are independent: the whole batch in two launches
+            return self._sample(x)
+        return super().sample(x)
 
     def none_like(self, x):
         return torch.zeros_like(x)

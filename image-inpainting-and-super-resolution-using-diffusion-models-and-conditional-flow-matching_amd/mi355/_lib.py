@@ -73,6 +73,7 @@ SIGNATURES = {
     "mi355_unet_destroy": (None, [_VP]),
     "mi355_unet_workspace_bytes": (_I64, [_VP, _I]),
     "mi355_unet_forward": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP, _I, _VP, _I64, _VP]),
+    "mi355_unet_forward_t": (_I, [_VP, _VP, _I, _VP, _I, _F, _VP, _I, _VP, _I64, _VP]),
     "mi355_unet_vjp": (_I, [_VP, _VP, _VP, _I, _I, _VP, _I64, _VP]),
     "mi355_unet_plan_op": (_I, [_VP, _I, C.POINTER(C.c_int32)]),
     "mi355_unet_read_tensor": (_I, [_VP, _I, _I, _VP, _I, _VP, _I64, _VP]),
@@ -93,6 +94,8 @@ SIGNATURES = {
     "mi355_ema_update": (_I, [_VP, _VP, _F, _F, _I64, _VP]),
     "mi355_mse_per_sample": (_I, [_VP, _VP, _VP, C.c_int, _I64, _VP]),
     "mi355_lincomb_per_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I64, _VP]),
+    "mi355_resize_bilinear": (_I, [_VP, _VP, _I64, _I, _I, _I, _I, _VP]),
+    "mi355_paint_patch": (_I, [_VP, _VP, _VP, _I, _F, _I, _VP, _I, _I, _I, _I, _VP]),
     "mi355_quantize_u8": (_I, [_VP, _VP, _I64, _VP]),
     "mi355_to_unit_range": (_I, [_VP, _VP, _I64, _VP]),
     "mi355_randn": (_I, [_VP, _U64, _U64, _I64, _VP]),

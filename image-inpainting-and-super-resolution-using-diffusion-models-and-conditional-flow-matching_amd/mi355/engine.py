@@ -101,8 +101,17 @@ class UNetEngine:
             raise ValueError(f"x ({Cx}) + condition ({Cc}) channels != in_channels ({self.in_channels})")
         return B, Cx, Cc
 
-    def forward(self, x: torch.Tensor, t: torch.Tensor, cond: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, t, cond: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        """t: a [B] device tensor, or a host scalar shared by the batch (no device tensor is made for it: mi355_unet_forward_t)."""
         B, Cx, Cc = self._split(x, cond)
+        if isinstance(t, (int, float)):
+            if out is None:
+                out = torch.empty(B, self.out_channels, self.image_size, self.image_size, device=self.device, dtype=torch.float32)
+            ws, wsb = self.workspace(B)
+            check(self.L.mi355_unet_forward_t(self.handle, self._chk(x, "x"), Cx, self._chk(cond, "condition") if cond is not None else None,
+                                              Cc, float(t), self._chk(out, "out"), B, ws, wsb, self._stream()), "mi355_unet_forward_t")
+            self._fwd_state = (B, self._ws.data_ptr())
+            return out
         if t.shape != (B,):
             raise ValueError(f"timesteps must have shape ({B},)")
         if out is None:

@@ -138,6 +138,27 @@ class Ops:
                                                   _req(b, "b") if b is not None else None, B, x[0].numel(), _stream()))
         return out
 
+    def resize_bilinear(self, x, size):
+        """F.interpolate(x, size=size, mode="bilinear", align_corners=False) on an NCHW fp32 device tensor (HIP kernel)."""
+        if x.dim() != 4:
+            raise ValueError("resize_bilinear expects an NCHW tensor")
+        Ho, Wo = int(size[0]), int(size[1])
+        out = torch.empty(x.shape[0], x.shape[1], Ho, Wo, device=x.device, dtype=torch.float32)
+        check(_lib.lib().mi355_resize_bilinear(_req(x, "x"), _req(out, "out"), x.shape[0] * x.shape[1], x.shape[2], x.shape[3], Ho, Wo,
+                                               _stream()), "mi355_resize_bilinear")
+        return out
+
+    def paint_patch(self, images, top, left, patch_size, pad_value, outpaint=False):
+        """InPainting / OutPainting condition of a whole batch: window (top[n], left[n]) of image n (int32 device tensors [N])."""
+        N, Cc, H, W = images.shape
+        if tuple(top.shape) != (N,) or tuple(left.shape) != (N,):
+            raise ValueError("top / left must have one entry per image")
+        out = torch.empty_like(images)
+        check(_lib.lib().mi355_paint_patch(_req(images, "images"), _req(top, "top", torch.int32), _req(left, "left", torch.int32),
+                                           int(patch_size), float(pad_value), int(bool(outpaint)), _req(out, "out"), N, Cc, H, W, _stream()),
+              "mi355_paint_patch")
+        return out
+
     def quantize_u8(self, x):
         out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
         check(_lib.lib().mi355_quantize_u8(_req(x, "x"), _req(out, "out", torch.uint8), x.numel(), _stream()))

@@ -17,7 +17,6 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
 
 from image_diffusion.unet import UNetModel
 from mi355.ops import default_ops
@@ -56,6 +55,8 @@ class UNetModelWrapper(UNetModel):
                          use_new_attention_order=use_new_attention_order, precision=precision)
 
     def _t(self, t, x):
+        if isinstance(t, (int, float)) or (isinstance(t, torch.Tensor) and t.dim() == 0 and not t.is_cuda):
+            return float(t)          # one host-side time for the batch: the engine broadcasts it (no device tensor, no ATen kernel)
         t = torch.as_tensor(t, device=x.device).float()
         while t.dim() > 1:
             t = t[:, 0]
@@ -63,9 +64,15 @@ class UNetModelWrapper(UNetModel):
             t = t.repeat(x.shape[0])
         return t
 
+    @staticmethod
+    def _c(t):
+        return t if isinstance(t, float) else t.contiguous()
+
     @torch.no_grad()
     def forward(self, t, x, y=None, *args, **kwargs):
-        return super().forward(x, self._t(t, x))
+        if not x.is_cuda:
+            return super().forward(x, t)     # raises MI355BackendError (no CPU path)
+        return self.engine(x.device).forward(x.float().contiguous(), self._c(self._t(t, x)))
 
 
 class InPaintModelWrapper(UNetModelWrapper):
@@ -77,7 +84,7 @@ class InPaintModelWrapper(UNetModelWrapper):
     @torch.no_grad()
     def forward(self, x, t, con=None, **kwargs):
         eng = self.engine(x.device)
-        return eng.forward(x.float().contiguous(), self._t(t, x).contiguous(), cond=con.float().contiguous())
+        return eng.forward(x.float().contiguous(), self._c(self._t(t, x)), cond=con.float().contiguous())
 
 
 class SuperResModelWrapper(UNetModelWrapper):
@@ -87,11 +94,15 @@ class SuperResModelWrapper(UNetModelWrapper):
     def __init__(self, dim, *a, **kw):
         super().__init__(dim, *a, in_channels=2 * dim[0], **kw)
 
+    def upsample(self, low_res, size):
+        """bilinear, align_corners=False (mnist/utils_mnist_hy.py:18-28 is the matching downsample): the HIP resize kernel"""
+        return default_ops.resize_bilinear(low_res.float().contiguous(), size)
+
     @torch.no_grad()
     def forward(self, x, t, low_res=None, **kwargs):
-        up = F.interpolate(low_res, (x.shape[2], x.shape[3]), mode="bilinear")
+        up = self.upsample(low_res, (x.shape[2], x.shape[3]))
         eng = self.engine(x.device)
-        return eng.forward(x.float().contiguous(), self._t(t, x).contiguous(), cond=up.float().contiguous())
+        return eng.forward(x.float().contiguous(), self._c(self._t(t, x)), cond=up)
 
 
 class NeuralODE:
@@ -112,7 +123,8 @@ class NeuralODE:
         return self
 
     def _call(self, t, x):
-        tt = torch.tensor(float(t), device=x.device, dtype=torch.float32)
+        # the library's own wrappers take the host scalar as it is; any other vector field gets the 0-dim tensor torchdyn passes
+        tt = float(t) if isinstance(self.vf, UNetModelWrapper) else torch.tensor(float(t), device=x.device, dtype=torch.float32)
         try:
             return self.vf(tt, x)
         except TypeError:
@@ -134,7 +146,7 @@ class NeuralODE:
             return traj
         out = [x.clone()]
         for k in range(len(ts) - 1):
-            t = torch.tensor(ts[k], device=x.device, dtype=torch.float32)
+            t = ts[k] if isinstance(self.vf, UNetModelWrapper) else torch.tensor(ts[k], device=x.device, dtype=torch.float32)
             try:
                 v = self.vf(t, x)
             except TypeError:

@@ -47,7 +47,10 @@ def sample(x):
 
 
 def downsample_images(images, target_size):
-    """utils_mnist_hy.py:18-28."""
+    """utils_mnist_hy.py:18-28: F.interpolate(images, size, mode="bilinear", align_corners=False); device tensors go through the HIP
+    resize kernel, CPU tensors (data-loader side) keep the eager call."""
+    if images.is_cuda:
+        return default_ops.resize_bilinear(images.float().contiguous(), tuple(target_size))
     return F.interpolate(images, size=target_size, mode="bilinear", align_corners=False)
 
 
@@ -103,13 +106,15 @@ def _euler_conditional(model, x_0, cond, steps, drift=True):
     ts = torch.linspace(0, 1, steps + 1).tolist()
     x = x_0.detach().clone().float().contiguous()
     if isinstance(model, (InPaintModelWrapper, SuperResModelWrapper)) and x.is_cuda:
-        c = cond if isinstance(model, InPaintModelWrapper) else F.interpolate(cond, (x.shape[2], x.shape[3]), mode="bilinear")
+        # bilinear up-sampling is linear, so the drifting low-res condition (con_{k+1} = (1 + dt) con_k) may be up-sampled ONCE per
+        # solve and drifted at full size: up((1 + dt) c) = (1 + dt) up(c)
+        c = cond if isinstance(model, InPaintModelWrapper) else model.upsample(cond, (x.shape[2], x.shape[3]))
         model.engine(x.device).cfm_euler(x, ts, cond=c.float().contiguous(), cond_drift=drift)
         return x, steps
     kw = "con" if not isinstance(model, SuperResModelWrapper) else "low_res"
     c = cond.detach().clone().float().contiguous()
     for k in range(steps):
-        t = torch.tensor(ts[k], device=x.device)
+        t = ts[k] if isinstance(model, (InPaintModelWrapper, SuperResModelWrapper)) else torch.tensor(ts[k], device=x.device)
         v = model.forward(x, t, **{kw: c})
         default_ops.euler_step_(x, v.float().contiguous(), ts[k + 1] - ts[k])
         if drift:
@@ -123,8 +128,10 @@ def _dopri5_conditional(model, x_0, cond, kw):
     the condition itself, so the condition the model sees drifts like e^t along the solve, and it takes part in the error norm."""
     from mi355.ode import odeint_dopri5
 
+    host_t = isinstance(model, (InPaintModelWrapper, SuperResModelWrapper))   # the wrappers take the solver's host scalar as it is
+
     def f(t, st):
-        tt = torch.tensor(float(t), device=st[0].device)
+        tt = float(t) if host_t else torch.tensor(float(t), device=st[0].device)
         return (model.forward(st[0], tt, **{kw: st[1]}), st[1])
 
     (x, _), nfe = odeint_dopri5(f, (x_0.float().contiguous(), cond.float().contiguous()), 0.0, 1.0, 1e-4, 1e-4)

@@ -85,6 +85,11 @@ int64_t mi355_unet_workspace_bytes(const mi355_unet* net, int batch);
 int mi355_unet_forward(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels,
                        const float* t, float* out, int batch, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same with ONE host-side time for the whole batch (the ODE solvers call the vector field as f(t, x) with a scalar t:
+ * cifar10/utils_cifar.py:34-39, mnist/utils_mnist.py:96-97): one time-embedding row instead of B, no device tensor for t. */
+int mi355_unet_forward_t(mi355_unet* net, const float* x, int x_channels, const float* cond, int cond_channels, float t, float* out,
+                         int batch, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Vector-Jacobian product of the last mi355_unet_forward on this workspace w.r.t. its image input: grad_x = (d out / d x)^T grad_out
  * (and, when cond was given, nothing for cond).  This is the `grad(constraint)` through the x0 model of the reconstruction-guidance
  * sampler (AD/image_diffusion/sampling.py:154-163; per-sample losses make vmap(grad) one batched backward pass).
@@ -235,6 +240,18 @@ int mi355_mse_per_sample(const float* a, const float* b, float* out, int batch, 
  * (AD/image_diffusion/sde_diffusion.py:214-244), whose coefficients are `extract`ed per sample (sde_diffusion.py:101-104). */
 int mi355_lincomb_per_sample(float* out, const float* x, const float* y, const float* a, const float* b, int batch,
                              int64_t elems_per_sample, void* stream);
+/* Condition builders (once per batch / per solve, never per step).
+ *   resize_bilinear: F.interpolate(x, size=(h_out, w_out), mode="bilinear", align_corners=False) on `planes` = N*C fp32 planes:
+ *                    downsample_images (mnist/utils_mnist_hy.py:18-28), HyperResolution._sample / .loss
+ *                    (AD/image_diffusion/likelihoods.py:119-126,138-143), the SuperRes wrapper's up-sampling of `low_res`
+ *                    (mnist/utils_mnist_hy.py:82).
+ *   paint_patch    : InPainting._sample / OutPainting._sample (likelihoods.py:78-87,95-104) for the whole batch: image n's
+ *                    patch_size x patch_size window at (top[n], left[n]) (device int32 arrays, drawn by the caller in the
+ *                    reference's order, likelihoods.py:22-27,49-53) becomes pad_value (outpaint = 0) or is the only part kept
+ *                    (outpaint = 1). */
+int mi355_resize_bilinear(const float* in, float* out, int64_t planes, int h_in, int w_in, int h_out, int w_out, void* stream);
+int mi355_paint_patch(const float* images, const int32_t* top, const int32_t* left, int patch_size, float pad_value, int outpaint,
+                      float* out, int batch, int channels, int h, int w, void* stream);
 /* (x*127.5+128).clip(0,255).to(uint8)  cifar10/compute_fid.py:87 */
 int mi355_quantize_u8(const float* x, uint8_t* out, int64_t n, void* stream);
 /* x.clip(-1,1)/2 + 0.5  cifar10/utils_cifar.py:40-41 */

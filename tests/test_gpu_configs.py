@@ -255,6 +255,111 @@ def test_cfg5_px128_freeform_amortized_ddpm_and_ddim_vs_oracle():
     assert torch.isfinite(got16).all() and rms < 0.05
 
 
+# ---- (d2) cfg 4 / cfg 5 at the MEASURED batch (task 2) -------------------------------------------------------------------
+# The bench lines of these configurations run B = 256 (64x64) and B = 128 (128 px): there every 3x3 conv of the large levels takes
+# conv3x3_ws_kernel (FiLM-folded prologue, affine_pool pre-pass, two-source concat), the 128-px net runs attention_kernel at
+# T = 1024 - paths a B = 1 run never enters (fewer tiles than CUs).  Same trick as cfg 2: the whole batch on the GPU, the CPU oracle
+# on a few of its images.
+
+FLOWERS = dict(image_size=64, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(4,),
+               channel_mult=(1, 2, 3, 4), num_heads=4, num_head_channels=64, use_scale_shift_norm=True, resblock_updown=True)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg4_flowers64_b256_forward_and_euler_vs_oracle(precision):
+    """BASELINE config 4 shard at its measured batch: Flowers-64 U-Net (AD/experiments/config.py:108-116: FiLM, up/down ResBlocks),
+    in = 6 = x || bilinear(16 -> 64) low-res image, B = 256: one forward with per-sample t and a 2-step Euler trajectory against the
+    CPU oracle on images {0, 255}.  fp32: the whole-forward tolerance; bf16: bounded against the output scale."""
+    net, sd = _net(FLOWERS, 1236, precision)
+    cfg = _cfg(FLOWERS)
+    B, pick = 256, [0, 255]
+    x = randn(4301, B, 3, 64, 64)
+    up = F.interpolate(rand_uniform(4302, -1.0, 1.0, B, 3, 16, 16), (64, 64), mode="bilinear").contiguous()
+    t = torch.linspace(0.0, 1.0, B)
+    eng = net.engine(DEV)
+    y = eng.forward(x.to(DEV), t.to(DEV), cond=up.to(DEV)).cpu()
+    ref = unet_ref.unet_forward(sd, cfg, torch.cat((x[pick], up[pick]), dim=1), t[pick])
+    emax, scale, rms = _report(f"cfg4 B=256 forward {precision}", y[pick], ref)
+    if precision == "fp32":
+        torch.testing.assert_close(y[pick], ref, rtol=2e-4, atol=5e-5)
+    else:
+        assert emax < 0.04 * scale and rms < 0.02
+    ts = torch.linspace(0, 1, 3)
+    xr = cfm_ref.euler_trajectory(lambda tt, xx: unet_ref.unet_forward(sd, cfg, torch.cat((xx, up[pick]), dim=1), tt.repeat(xx.shape[0])),
+                                  x[pick], ts, keep_all=False)
+    xg = x.to(DEV).clone()
+    eng.cfm_euler(xg, ts.tolist(), cond=up.to(DEV))
+    emax, scale, rms = _report(f"cfg4 B=256 2-step Euler {precision}", xg.cpu()[pick], xr)
+    if precision == "fp32":
+        torch.testing.assert_close(xg.cpu()[pick], xr, rtol=5e-4, atol=1e-4)
+    else:
+        assert emax < 0.03 * scale and rms < 0.01
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg5_px128_b128_forward_vs_oracle(precision):
+    """BASELINE config 5 shard at its measured batch: the 128-px net (create_model's 128 default mult, unet.py:68-69; attention at
+    32 / 16 / 8), in = 6, B = 128: one forward against the CPU oracle on image 127 (a 109-GFLOP CPU forward)."""
+    net, sd = _net(PX128, 1237, precision)
+    cfg = _cfg(PX128)
+    B, pick = 128, [127]
+    x = randn(4401, B, 3, 128, 128)
+    cond = rand_uniform(4402, -1.0, 1.0, B, 3, 128, 128)
+    mask = free_form_mask(4403, 8, 128, 128, 0.4).repeat(B // 8, 1, 1, 1)
+    cond = torch.where(mask.expand_as(cond), torch.full_like(cond, -2.0), cond).contiguous()
+    t = torch.linspace(0.0, 1.0, B)
+    y = net.engine(DEV).forward(x.to(DEV), t.to(DEV), cond=cond.to(DEV)).cpu()
+    ref = unet_ref.unet_forward(sd, cfg, torch.cat((x[pick], cond[pick]), dim=1), t[pick])
+    emax, scale, rms = _report(f"cfg5 B=128 forward {precision}", y[pick], ref)
+    if precision == "fp32":
+        torch.testing.assert_close(y[pick], ref, rtol=2e-4, atol=5e-5)
+    else:
+        assert emax < 0.04 * scale and rms < 0.02
+
+
+def test_utils_mnist_hy_generate_samples_eval_64px_on_gpu():
+    """mnist/utils_mnist_hy.py:76-98 (the ACTIVE 3x64x64 super-resolution sampler of train_mnist_hy.py): dopri5 over the tuple state
+    (x, low_res), low_res = bilinear 64 -> 16 of the test images, model.forward(x, t, low_res=...) - on the GPU against
+    oracle/cfm_ref.dopri5 ('parity unpinned': torchdiffeq is not vendored), and its Euler form against the drifting-condition
+    restatement.  num_channels 32 keeps the CPU solve short; the reference's wrapper keywords otherwise."""
+    import utils_mnist_hy
+    from image_diffusion.unet import param_shapes
+    from torchcfm_compat import SuperResModelWrapper
+
+    s = SuperResModelWrapper(dim=(3, 64, 64), num_channels=32, num_res_blocks=1, num_classes=None, class_cond=True, precision="fp32")
+    ssd = synth_state_dict(param_shapes(s), 1243)
+    s.load_state_dict(ssd)
+    s.to(DEV)
+    imgs = rand_uniform(47, -1, 1, 2, 3, 64, 64).to(DEV)
+    scfg = unet_ref.UNetConfig(64, 6, 32, 3, 1, (4,), channel_mult=(1, 2, 3, 4))   # _default_mult(64); "16" -> ds 4; one head
+    up = lambda c: F.interpolate(c, (64, 64), mode="bilinear")
+    torch.manual_seed(9)
+    traj, low, nfe = utils_mnist_hy.generate_samples_eval(s, imgs, batch_size=2)
+    assert traj.shape == (2, 3, 64, 64) and low.shape == (2, 3, 16, 16) and nfe > 0
+    torch.testing.assert_close(low.cpu(), F.interpolate(imgs.cpu(), size=(16, 16), mode="bilinear", align_corners=False))
+    torch.manual_seed(9)
+    x0 = torch.randn(2, 3, 64, 64, device=DEV)
+    fs = lambda t, st: (unet_ref.unet_forward(ssd, scfg, torch.cat((st[0], up(st[1])), dim=1), t.reshape(1).repeat(2)), st[1])
+    (xr, _), nfe_ref = cfm_ref.dopri5(fs, (x0.cpu(), low.cpu()), 0.0, 1.0, 1e-4, 1e-4)
+    _report(f"utils_mnist_hy dopri5 (nfe {nfe} vs {nfe_ref})", traj.cpu(), xr.clip(-1, 1))
+    torch.testing.assert_close(traj.cpu(), xr.clip(-1, 1), rtol=3e-3, atol=3e-3)
+    # Euler form (solver="euler"): the concatenated-state sampler, the low-res condition drifts and is upsampled once per solve
+    torch.manual_seed(10)
+    traj, low, nfe = utils_mnist_hy.generate_samples_eval(s, imgs, batch_size=2, solver="euler", steps=8)
+    torch.manual_seed(10)
+    x0 = torch.randn(2, 3, 64, 64, device=DEV)
+    # restated inline (the reference has no Euler form of THIS sampler; it is utils_mnist2.py:118-138's loop with the wrapper's
+    # low_res keyword): x_{k+1} = x_k + dt f(x_k, t_k, up(c_k)), c_{k+1} = c_k + dt c_k at LOW resolution
+    xr, c = x0.cpu().clone(), low.cpu().clone()
+    tsp = torch.linspace(0, 1, 9)
+    for k in range(8):
+        dt = tsp[k + 1] - tsp[k]
+        xr = xr + dt * unet_ref.unet_forward(ssd, scfg, torch.cat((xr, up(c)), dim=1), tsp[k].repeat(2))
+        c = c + dt * c
+    assert nfe == 8
+    torch.testing.assert_close(traj.cpu(), xr.clip(-1, 1), rtol=2e-3, atol=5e-4)
+
+
 # ---- (e) cfg 1: the MNIST net through the sampler loops ---------------------------------------------------------------------------
 
 MNIST = dict(image_size=28, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=(1,),

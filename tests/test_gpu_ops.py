@@ -197,3 +197,53 @@ def test_ema_update_matches_reference_expression(ops):
         ref = t * decay + s * (1 - decay)
         got = ops.ema_update_(t.clone().to(DEV), s.to(DEV), decay).cpu()
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("shape,size", [((3, 3, 64, 64), (16, 16)), ((2, 3, 16, 16), (64, 64)), ((5, 1, 28, 28), (7, 7)), ((5, 1, 7, 7), (28, 28)),
+                                        ((2, 2, 13, 9), (31, 20)), ((1, 1, 5, 5), (5, 5))])
+def test_resize_bilinear_vs_torch(ops, shape, size):
+    """mi355_resize_bilinear = F.interpolate(mode="bilinear", align_corners=False): downsample_images (mnist/utils_mnist_hy.py:18-28),
+    HyperResolution._sample (likelihoods.py:119-126), the SuperRes wrapper's up-sampling.  fp32: 1e-6 (same taps, same weights; only
+    the contraction of the four products may differ)."""
+    x = randn(500 + shape[2], *shape)
+    want = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    got = ops.resize_bilinear(x.to(DEV), size).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    # linearity (what lets the drifting low-res condition be up-sampled once per solve): up(a x) == a up(x) to rounding
+    a = 1.0 + 1.0 / 99
+    torch.testing.assert_close(ops.resize_bilinear((x * a).to(DEV), size).cpu(), got * a, rtol=1e-6, atol=1e-6)
+
+
+def test_likelihood_builders_on_device_match_the_host_loop():
+    """Likelihood.sample (likelihoods.py:22-27: one draw per image in a Python loop): on device tensors the draws stay on the host in
+    the same order and the tensor work is one launch - bit-identical to the CPU path under the same seed, for all three types."""
+    from image_diffusion.likelihoods import HyperResolution, InPainting, OutPainting
+
+    x = rand_uniform(77, -1.0, 1.0, 9, 3, 32, 32)
+    for lik in (InPainting(8, -2.0), OutPainting(12, -2.0)):
+        torch.manual_seed(3)
+        want = lik.sample(x)
+        torch.manual_seed(3)
+        got = lik.sample(x.to(DEV))
+        assert got.is_cuda and torch.equal(got.cpu(), want)
+        assert float((want == -2.0).float().mean()) > 0
+    h = HyperResolution(16, 16)
+    torch.testing.assert_close(h.sample(x.to(DEV)).cpu(), h.sample(x), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(h.loss(x.to(DEV), h.sample(x.to(DEV))).cpu(), h.loss(x, h.sample(x)), rtol=1e-5, atol=1e-7)
+
+
+def test_forward_with_host_scalar_time_matches_tensor_time():
+    """mi355_unet_forward_t (one host-side time for the batch, as the ODE solvers call the field) == mi355_unet_forward with t.repeat(B) (to fp32 rounding)."""
+    from image_diffusion.unet import UNetModel, param_shapes
+
+    net = UNetModel(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,),
+                    channel_mult=(1, 2), num_heads=2, precision="fp32")
+    net.load_state_dict(synth_state_dict(param_shapes(net), 31))
+    net.to(DEV)
+    eng = net.engine(DEV)
+    for B in (1, 3, 17):
+        x = randn(600 + B, B, 3, 16, 16).to(DEV)
+        a = eng.forward(x, 0.37)
+        b = eng.forward(x, torch.full((B,), 0.37, device=DEV))
+        # one embedding row broadcast vs B identical rows: the small linear kernels sum in a batch-size-dependent order (fp32 rounding)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-6)
