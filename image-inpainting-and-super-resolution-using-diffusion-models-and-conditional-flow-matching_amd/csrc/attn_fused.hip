@@ -328,8 +328,8 @@ int launch_fused(const AttnFuseArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch) {
-  static const int enabled = getenv("MI355_ATTN_FUSE") ? atoi(getenv("MI355_ATTN_FUSE")) : 1;
+bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch, const mi355_debug_config* knobs) {
+  const int enabled = (knobs ? knobs : &mi355_default_debug())->attn_fused;
   const int CHUNK = dtype == 0 ? 16 : 32;
   (void)CHUNK;
   return enabled && ch == 64 && heads * ch == C && (T == 128 || T == 256) && C % 128 == 0 && C <= 512;   // 3C % 128 == 0: 128-row weight tiles

@@ -23,9 +23,24 @@ static size_t emb_table_bytes(const mi355_unet* net) {
 
 static UnetRun uniform_t_run();
 
+const mi355_debug_config& mi355_default_debug() {
+  static const mi355_debug_config d = [] { mi355_debug_config c; mi355_debug_defaults(&c); return c; }();
+  return d;
+}
+
 extern "C" {
 
-int mi355_version(void) { return 100; }
+int mi355_version(void) { return 101; }
+void mi355_debug_defaults(mi355_debug_config* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->conv_ws = 1; c->conv_small = 1; c->conv_min_wgs = 512; c->conv_stagger = 0; c->conv_ablate = 0; c->conv_spin_limit = 1 << 22;
+  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_pass = 1;
+}
+int mi355_unet_status(mi355_unet* net, int clear) {
+  if (!net) { mi355_set_error("null handle"); return -1; }
+  return unet_status(net, clear);
+}
 const char* mi355_last_error(void) { return g_err.c_str(); }
 
 int mi355_unet_param_count(const mi355_unet_config* cfg) {
@@ -382,8 +397,9 @@ int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw) {
 
 int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
                  int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
-                 const float* emb, const float* res, int res_mode, int dtype, void* workspace, int64_t workspace_bytes,
-                 void* stream) {
+                 const float* emb, const float* res, int res_mode, int dtype, const mi355_debug_config* debug, void* workspace,
+                 int64_t workspace_bytes, void* stream) {
+  const mi355_debug_config& K = debug ? *debug : mi355_default_debug();
   MI355_REQUIRE(x && w_host && y && workspace, -1, "conv2d: null argument");
   MI355_REQUIRE(dtype == 0 || dtype == 1, -1, "conv2d: bad dtype");
   MI355_REQUIRE(stride == 1 || stride == 2, -1, "conv2d: stride must be 1 or 2");
@@ -396,6 +412,7 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   const int cpad = (cin + CH - 1) / CH * CH;
   const int ctot = cin + cin1, ctot_pad = cpad + cin1;
   ConvDesc d; d.dtype = dtype; d.N = batch; d.Hs = h; d.Ws = w; d.C0 = cpad; d.C1 = cin1; d.ks = ksize; d.Cout = cout;
+  d.knobs = &K;
   const bool pool = resample == 3;   // 2x2 average pool of the (normalised) input: a pre-pass, then a plain conv
   MI355_REQUIRE(!(pool && x1), -4, "conv2d: pooling over a channel concat is not supported");
   if (pool) { d.Hs = h / 2; d.Ws = w / 2; }
@@ -415,7 +432,10 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   void* yout = p; p += al256((size_t)batch * g.Ho * g.Wo * cout * esz);
   void* rin = p; if (res) p += al256((size_t)batch * Hr * Wr * cout * esz);
   void* xpool = p; if (pool) p += al256((size_t)batch * (h / 2) * (w / 2) * cpad * esz);
+  uint32_t* errw = reinterpret_cast<uint32_t*>(p); p += 256;
   MI355_REQUIRE(p <= end, -2, "conv2d: workspace too small");
+  MI355_CHECK_HIP(hipMemsetAsync(errw, 0, 256, s));
+  d.err = errw;
   int rc;
   if ((rc = pack_nhwc_launch(dtype, x, cin, nullptr, 0, batch, h * w, cpad, xin, s))) return rc;
   if (x1 && (rc = pack_nhwc_launch(dtype, x1, cin1, nullptr, 0, batch, h * w, cin1, xin1, s))) return rc;
@@ -449,8 +469,8 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   d.dbg = p;
 #endif
   if ((rc = conv_launch(d, s))) return rc;
-  if (const char* reps_s = getenv("MI355_CONV_TIME")) {   // diagnostic: average duration of the conv launch alone
-    const int reps = atoi(reps_s) > 0 ? atoi(reps_s) : 20;
+  if (K.conv_time_reps > 0) {   // diagnostic: average duration of the conv launch alone
+    const int reps = K.conv_time_reps;
     hipEvent_t e0, e1;
     MI355_CHECK_HIP(hipEventCreate(&e0)); MI355_CHECK_HIP(hipEventCreate(&e1));
     MI355_CHECK_HIP(hipEventRecord(e0, s));
@@ -465,6 +485,11 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   }
   if (nhwc && (rc = unpack_nchw_launch(dtype, yout, batch, g.Ho * g.Wo, cout, y, s))) return rc;
   MI355_CHECK_HIP(hipStreamSynchronize(s));  // `packed` is a temporary host buffer
+  {
+    uint32_t ev = 0;
+    MI355_CHECK_HIP(hipMemcpy(&ev, errw, 4, hipMemcpyDeviceToHost));
+    if (ev) { mi355_set_error("conv2d: the persistent kernel gave up a bounded counter wait (hand-over stalled): the output is invalid"); return MI355_ERR_TIMEOUT; }
+  }
 #ifdef CONV_STAMPS
   {
     std::vector<unsigned long long> hv(nwaves * 8);
@@ -472,7 +497,7 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
     static const char* names_plain[8] = {"setup", "commit_patch", "barrier_A", "commit_w(+vmcnt)", "barrier_B", "prefetch_issue", "mma", "epilogue"};
     // warp-specialised kernel: slots 0-4 are written by loader waves only, 5-7 by consumer waves only (half the waves each)
     static const char* names_ws[8] = {"L:fill", "L:commit_w", "L:commit_frag", "L:issue", "L:barrier", "C:barrier", "C:mma_row", "C:epilogue+setup"};
-    const bool ws_names = !getenv("MI355_CONV_WS") || atoi(getenv("MI355_CONV_WS")) != 0;
+    const bool ws_names = K.conv_ws != 0;
     const char** names = ws_names ? names_ws : names_plain;
     double h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
     for (size_t w = 0; w < nwaves; ++w) for (int k = 0; k < 8; ++k) h[k] += (double)hv[w * 8 + k];

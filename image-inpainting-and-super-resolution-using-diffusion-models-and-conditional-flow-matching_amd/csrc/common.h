@@ -126,6 +126,11 @@ int mi355_allow_big_lds(K kern, const char* what) {
 // (loads return in order within a wave, so a working wave would wait for the cold lines before its own data; a wave that has ended
 // does not take part in later barriers).  Workgroup b runs on XCD b % 8 (one L2 each): the extra waves of every XCD cover the whole
 // range once, one 128-B line per lane and step.
+// NB (the HIP programming model does not promise this): the extra wave RETURNS before the barriers its workgroup runs later.  On
+// gfx9-family hardware s_barrier counts the waves of the workgroup that are still alive, so a wave that has ended is not waited
+// for (the same property every `if (tid >= n) return;` tail in front of a __syncthreads() relies on); the HIP specification calls a
+// barrier not reached by all threads undefined.  This library targets gfx950 only; if that ever changes, give the warm-up its own
+// launch (it was measured as such in round 2: the extra launch costs more than the warm-up gains).
 __device__ __forceinline__ void l2_warm_wave(const void* p, uint32_t bytes) {
   const uint32_t rank = blockIdx.x >> 3, per = (gridDim.x + 7) >> 3, step = per * 64u * 128u;
   const char* base = reinterpret_cast<const char*>(p);

@@ -45,6 +45,8 @@ struct ConvKArgs {
   unsigned long long* dbg;           // diagnostic build only (-DCONV_STAMPS): per-phase cycle sums
   int ablate;                        // diagnostic build only: 1 = no output stores, 2 = no prologue math, 4 = no MFMA
   int stagger;                       // odd-slot workgroup start delay in units of s_sleep(127) (~8k cycles each)
+  uint32_t* err;                     // error word (device-visible): bit 0 = a counter wait of the persistent kernel expired
+  int spin_limit;                    // polls before such a wait gives up
 };
 
 #ifdef CONV_STAMPS
@@ -593,7 +595,7 @@ int compute_geo(const ConvDesc& d, Geo& g) {
   if (Q != P) { cand[nc][0] = 64; cand[nc++][1] = Q; }
   int bestBM = cand[nc - 1][0], bestBN = cand[nc - 1][1];
   const long img_slots = (long)(1 << ilog2_ceil(g.Wo)) * (1 << ilog2_ceil(g.Ho));
-  static const long min_wgs = getenv("MI355_CONV_MINWG") ? atol(getenv("MI355_CONV_MINWG")) : 512;
+  const long min_wgs = (d.knobs ? d.knobs : &mi355_default_debug())->conv_min_wgs;
   for (int i = 0; i < nc; ++i) {
     if (cand[i][0] == 128 && img_slots < 128) continue;   // several images per tile: only the 64-pixel tile has that variant
     const long wgs = ((M + cand[i][0] - 1) / cand[i][0]) * ((d.Cout + cand[i][1] - 1) / cand[i][1]);
@@ -694,7 +696,7 @@ ConvGeom conv_geometry(const ConvDesc& d) {
   r.grid_m = g.groups * g.tiles_x * g.tiles_y; r.grid_n = (d.Cout + g.BN - 1) / g.BN;
   const int CH = d.dtype == 0 ? 16 : 32;
   if (d.C0 % CH == 0 && d.C1 % CH == 0 &&
-      ws_eligible(d.ks, g.BM, g.BN, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.N, g.Ho, g.Wo, d.Cout)) {
+      ws_eligible((d.knobs ? d.knobs : &mi355_default_debug())->conv_ws, d.ks, g.BM, g.BN, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.N, g.Ho, g.Wo, d.Cout)) {
     r.BM = 256; r.lds_bytes = ws::LDS_BYTES;   // warp-specialised persistent kernel: 16 x 16 pixel tiles (grid_m / grid_n stay the plain launch's: workspace sizing)
   }
   return r;
@@ -734,8 +736,9 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   MI355_REQUIRE(ob < 0xFFFF0000ull && rb < 0xFFFF0000ull, -4, "conv: output tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.obytes = (uint32_t)ob; a.rbytes = d.res ? (uint32_t)rb : 0u;
   a.dbg = reinterpret_cast<unsigned long long*>(d.dbg);
-  { static const int stg = getenv("MI355_CONV_STAGGER") ? atoi(getenv("MI355_CONV_STAGGER")) : 0; a.stagger = stg; }
-  { static const int abl = getenv("MI355_CONV_ABLATE") ? atoi(getenv("MI355_CONV_ABLATE")) : 0; a.ablate = abl; }
+  const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
+  a.stagger = K.conv_stagger; a.ablate = K.conv_ablate;
+  a.err = d.err; a.spin_limit = K.conv_spin_limit > 0 ? K.conv_spin_limit : 1;
   a.emb = d.emb; a.emb_stride = d.emb_stride;
   a.res = d.res; a.res_mode = d.res ? d.res_mode : RES_NONE;
   a.out = d.out; a.out_mode = d.out_mode;
@@ -747,13 +750,13 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
     const int ws_slots = 2 * ((g.Wo + ws::VW - 1) / ws::VW) * ((g.Ho + ws::TH - 1) / ws::TH);   // (16x16 pixel tile, 8-row half) per image
     if (gn_ok && ws_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = ws_slots; }
-    const int r = d.dtype == 0 ? launch_ws<float>(a, g.BM, g.BN, d.ks, stream) : launch_ws<bf16>(a, g.BM, g.BN, d.ks, stream);
+    const int r = d.dtype == 0 ? launch_ws<float>(a, K.conv_ws, g.BM, g.BN, d.ks, stream) : launch_ws<bf16>(a, K.conv_ws, g.BM, g.BN, d.ks, stream);
     if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); if (gn_slots_used) *gn_slots_used = a.gn_slots; return 0; }
     if (r < 0) return r;
     a.gn_stats = nullptr; a.gn_slots = 0;
   }
   {   // 8x8 / 4x4 levels: barrier-free K loop over an LDS-resident patch, weights straight into registers (conv_small.inc.h)
-    const int r = d.dtype == 0 ? launch_small<float>(a, d.ks, stream) : launch_small<bf16>(a, d.ks, stream);
+    const int r = d.dtype == 0 ? launch_small<float>(a, K.conv_small, d.ks, stream) : launch_small<bf16>(a, K.conv_small, d.ks, stream);
     if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
     if (r < 0) return r;
   }

@@ -266,8 +266,7 @@ __global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Arg
 // levels normalise in a pass of their own), NHWC output with C_out % 128 == 0, residual at the output resolution or none.
 // 0 = launched, 1 = not eligible (the caller goes on to the plain kernel), < 0 = error
 template <typename T>
-int launch_small(const ConvKArgs& a0, int ks, hipStream_t s) {
-  static const int enabled = getenv("MI355_CONV_SMALL") ? atoi(getenv("MI355_CONV_SMALL")) : 1;
+int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s) {
   ConvKArgs a = a0;
   if (!enabled || ks != 3 || a.stride != 1 || a.out_mode != OUT_NHWC || a.pro_a) return 1;
   if (a.Ho != a.Wo || (a.Ho != 8 && a.Ho != 4) || a.Cout % 128 != 0) return 1;

@@ -26,7 +26,8 @@
 //     issued before the MFMAs of step s, and the hand-over to the next row sits between the last reads and the last
 //     MFMAs of the current row, so neither LDS latency nor the counter poll stalls the matrix pipe.
 // Every wait is a poll of a counter that the other role advances without waiting for the poller (a consumer at row R has
-// released R - 1, which is all the loaders need for row R + 1), bounded by a spin limit as a last resort (a wrong result, not a hang).
+// released R - 1, which is all the loaders need for row R + 1), bounded by a spin limit as a last resort: no hang, and the launch is
+// flagged (error word -> MI355_ERR_TIMEOUT at the C boundary).
 #ifndef WS_ABLATE
 #define WS_ABLATE 0   // diagnostic builds only: 4 = consumers skip LDS reads + MFMA, 8 = no weight loads, 16 = no patch loads, 64 = no weight LDS writes
 #endif
@@ -40,7 +41,9 @@ constexpr int BN = 128, WTILE = BN * 64, WIT = 3 * WTILE / (256 * 16);      // 6
 constexpr int CBUF = BN * 4;                                                // bias + emb of one tile's channels (f32)
 constexpr int NPLANES = 3, NWBUF = 4;                                        // patch planes / weight row buffers
 constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE + 2 * CBUF + 32;   // 161,568 B (+ the eight counters)
-constexpr int SPIN_LIMIT = 1 << 22;
+// Counter polls are bounded (p.spin_limit, default 1 << 22 polls of >= 64 cycles: seconds): a protocol bug or a wave that never arrives
+// ends in MI355_ERR_TIMEOUT instead of a hung GPU.  A wait that gives up ORs 1 into the launch's error word (p.err; cold path inside
+// the poll's asm block) and the wave goes on: the tile is wrong, the grid still drains.
 }  // namespace ws
 
 // GN affine (+ SiLU) of one 16-byte fragment.  bf16: fp32 math on element PAIRS (v_pk_fma/mul/add_f32: two elements per VALU
@@ -131,9 +134,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   // and the register allocator, already at the 256-VGPR limit there, answered with 16-byte scratch spills per row.  EXEC is all
   // ones at every call site (wave-uniform control flow only) and is restored; s_waitcnt lgkmcnt(0) also retires the wave's own
   // outstanding fragment reads, which it would have to wait for before the next row's MFMAs anyway.
+  // the launch's error word (conv_launch always passes one: the caller's, or a scratch word of the workspace)
+  const __attribute__((address_space(1))) uint32_t* errp = (const __attribute__((address_space(1))) uint32_t*)p.err;
   auto wait_ge = [&](const uint32_t* cp, uint32_t target) {
     const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)cp;
-    uint32_t v0, v1, v2, v3; int sv, spins = SPIN_LIMIT;
+    uint32_t v0, v1, v2, v3; int sv, spins = p.spin_limit;
     asm volatile(
         "1:\n\t"
         "ds_read_b32 %0, %6\n\t"
@@ -150,12 +155,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         "s_cbranch_scc1 2f\n\t"
         "s_sub_u32 %5, %5, 1\n\t"
         "s_cmp_eq_u32 %5, 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
+        "s_cbranch_scc1 4f\n\t"
         "s_sleep 1\n\t"
         "s_branch 1b\n\t"
+        "4:\n\t"                                  // gave up: flag the launch (one lane, no return value), then go on
+        "s_cmp_eq_u64 %8, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %0, 0\n\t"
+        "v_mov_b32 %1, 1\n\t"
+        "global_atomic_or %0, %1, %8\n\t"
+        "s_mov_b64 exec, -1\n\t"
         "2:"
         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&s"(sv), "+s"(spins)
-        : "v"(a), "s"(target)
+        : "v"(a), "s"(target), "s"(errp)
         : "scc", "memory");
   };
   // The consumers' row hand-over, split so that the poll's LDS round trip hides behind a half-tap of MFMAs: `poll_issue` reads the
@@ -173,7 +186,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     const uint32_t am = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)mine;
     const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)cp;
     const uint32_t one = 1u;
-    int sv, spins = SPIN_LIMIT;
+    int sv, spins = p.spin_limit;
     asm volatile(
         "s_mov_b64 exec, 1\n\t"
         "ds_add_u32 %7, %8\n\t"
@@ -195,12 +208,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         "s_cbranch_scc1 2f\n\t"
         "s_sub_u32 %5, %5, 1\n\t"
         "s_cmp_eq_u32 %5, 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
+        "s_cbranch_scc1 4f\n\t"
         "s_sleep 1\n\t"
         "s_branch 1b\n\t"
+        "4:\n\t"
+        "s_cmp_eq_u64 %10, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %0, 0\n\t"
+        "v_mov_b32 %1, 1\n\t"
+        "global_atomic_or %0, %1, %10\n\t"
+        "s_mov_b64 exec, -1\n\t"
         "2:"
         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&s"(sv), "+s"(spins)
-        : "v"(a), "v"(am), "v"(one), "s"(target)
+        : "v"(a), "v"(am), "v"(one), "s"(target), "s"(errp)
         : "scc", "memory");
   };
   auto bump = [&](uint32_t* cp) {
@@ -355,7 +376,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
           STAMP(3)
           wait_landed(k);
           STAMP(1)
-          bump(c_prod + wave8);        // this wave's share of kernel row (t, c, ky), and of every piece issued before this interval, is in LDS
+          if (!((p.ablate & 32) && R == 5)) bump(c_prod + wave8);        // this wave's share of kernel row (t, c, ky), and of every piece issued before this interval, is in LDS
           ++R;
           acquire_free();              // before anything of the next interval is issued
           STAMP(4)
@@ -553,7 +574,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
           STAMP(3)
           wait_landed();
           STAMP(1)                     // (diagnostic build: slot 1 = time spent in the counted wait)
-          bump(c_prod + wave8);        // this wave's share of kernel row (t, c, ky) and of its patch is in LDS
+          if (!((p.ablate & 32) && R == 5)) bump(c_prod + wave8);        // this wave's share of kernel row (t, c, ky) and of its patch is in LDS
           ++R;
           acquire_free();              // before anything of the next interval is written
           STAMP(4)
@@ -851,8 +872,7 @@ static int ws_num_cus() {
   static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; } return n; }();
   return ncu;
 }
-static bool ws_eligible(int ks, int BM, int BN, int G, int bn_pack, int out_mode, int stride, int nchunks, int N, int Ho, int Wo, int Cout) {
-  static const int enabled = getenv("MI355_CONV_WS") ? atoi(getenv("MI355_CONV_WS")) : 1;
+static bool ws_eligible(int enabled, int ks, int BM, int BN, int G, int bn_pack, int out_mode, int stride, int nchunks, int N, int Ho, int Wo, int Cout) {
   if (!enabled || ks != 3 || BM != 128 || BN != 128 || G != 1 || bn_pack != 128 || out_mode != OUT_NHWC) return false;
   if (stride != 1 || nchunks < 2 || (nchunks & 1)) return false;
   if (Wo < ws::VW || Ho < ws::TH) return false;
@@ -862,8 +882,8 @@ static bool ws_eligible(int ks, int BM, int BN, int G, int bn_pack, int out_mode
 
 // 0 = launched, 1 = not eligible (caller uses the plain kernel), < 0 = error
 template <typename T>
-int launch_ws(ConvKArgs a, int BM, int BN, int ks, hipStream_t s) {
-  if (!ws_eligible(ks, BM, BN, a.G, a.bn_pack, a.out_mode, a.stride, a.nchunks, a.N, a.Ho, a.Wo, a.Cout)) return 1;
+int launch_ws(ConvKArgs a, int enabled, int BM, int BN, int ks, hipStream_t s) {
+  if (!ws_eligible(enabled, ks, BM, BN, a.G, a.bn_pack, a.out_mode, a.stride, a.nchunks, a.N, a.Ho, a.Wo, a.Cout)) return 1;
   a.lvw = 4; a.lth = 4; a.PW = ws::PW; a.PH = ws::PH; a.NP = ws::NPX;
   a.tiles_x = (a.Wo + ws::VW - 1) / ws::VW; a.tiles_y = (a.Ho + ws::TH - 1) / ws::TH;
   const int n_mt = a.N * a.tiles_x * a.tiles_y, n_nt = (a.Cout + 127) / 128;

@@ -1,6 +1,9 @@
 // Internal C++ launch API shared by the U-Net executor, the sampler loops and the C ABI.
 #pragma once
 #include "common.h"
+#include "../../include/mi355_sampler.h"
+
+const mi355_debug_config& mi355_default_debug();   // the shipped behaviour (capi.hip)
 
 // ---- implicit-GEMM convolution -------------------------------------------------------------------
 // Activations are NHWC in HBM ([N][H][W][C], element type float or bf16).  out[n, y, x, co] =
@@ -33,6 +36,8 @@ struct ConvDesc {
   // per image; conv_launch reports the slots it filled (0 = this launch cannot produce them: the caller runs the stats kernel)
   float* gn_stats = nullptr; int gn_slots_cap = 0;
   void* dbg = nullptr;                      // diagnostic builds only (-DCONV_STAMPS): 9 x u64 phase-cycle sums
+  const mi355_debug_config* knobs = nullptr; // diagnostic switches (null = defaults)
+  uint32_t* err = nullptr;                  // device-visible error word: the persistent kernel ORs 1 into it when a counter wait expires
 };
 
 struct ConvGeom {
@@ -105,7 +110,7 @@ struct AttnFusedDesc {
   void* out = nullptr;
   int N = 0, T = 0, C = 0, heads = 0, ch = 0, new_order = 0;
 };
-bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch);
+bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch, const mi355_debug_config* knobs = nullptr);
 int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream);
 
 // ---- backward (data gradient only: reconstruction guidance, AD/image_diffusion/sampling.py:136-206) --------------------------------

@@ -42,6 +42,10 @@ struct PlanOp {
 
 struct mi355_unet {
   mi355_unet_config cfg;
+  mi355_debug_config knobs;        // diagnostic switches, copied at creation (cfg.debug is not kept)
+  // error word of the handle's launches: pinned host memory the kernels write through (mi355_unet_status); dev = its device address
+  uint32_t* err_host = nullptr; uint32_t* err_dev = nullptr;
+  ~mi355_unet();
   std::vector<ParamInfo> params;
   std::vector<PlanTensor> tensors;
   std::vector<PlanOp> ops;
@@ -78,6 +82,7 @@ struct UnetRun {
 int unet_build(const mi355_unet_config& cfg, const float* const* params_host, int n_params, void* dev_weights,
                int64_t dev_weights_bytes, hipStream_t stream, mi355_unet** out);
 int64_t unet_weight_bytes(const mi355_unet_config& cfg);
+int unet_status(const mi355_unet* net, int clear);   // 0 or MI355_ERR_TIMEOUT (+ message)
 int64_t unet_workspace_bytes(const mi355_unet* net, int batch);
 struct WsLayout { size_t temb, emb1, emb2, embp, gna, gnb, stats, sites, arena, grads, du, tmp, z, dy, ld, total; };
 WsLayout unet_ws_layout(const mi355_unet* net, int B);

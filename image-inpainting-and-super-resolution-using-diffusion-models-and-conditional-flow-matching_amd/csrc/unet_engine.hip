@@ -95,7 +95,7 @@ struct Walker {
   // that already holds silu?(GN(x)): at 8x8 and below the convs are latency-bound 64-pixel-tile launches whose prologue math
   // and per-image (a, b) loads sit on the critical path, while the GN kernel has the whole image in L2 anyway.
   int add_gn(int s0, int s1, const std::string& wname, const std::string& bname, int film_off, int apply_silu, bool may_apply = true) {
-    static const int max_hw = getenv("MI355_GN_APPLY_MAXHW") ? atoi(getenv("MI355_GN_APPLY_MAXHW")) : 64;
+    const int max_hw = net->knobs.gn_apply_max_hw;
     const int C = T(s0).C + (s1 >= 0 ? T(s1).C : 0);
     PlanOp op; op.kind = OP_GN; op.src0 = s0; op.src1 = s1;
     op.gamma_off = put_f32(wname, {C}); op.beta_off = put_f32(bname, {C}); op.film_emb_off = film_off;
@@ -110,7 +110,7 @@ struct Walker {
       // larger images: take the statistics from the partial sums the producing convs leave in their epilogues when the groups are
       // whole channel quads of each source (C multiple of 128 for GroupNorm32); decided per launch (a producer that cannot
       // provide them, e.g. a resample pass, leaves the site on the statistics kernel)
-      static const int fuse = getenv("MI355_GN_FUSE") ? atoi(getenv("MI355_GN_FUSE")) : 1;
+      const int fuse = net->knobs.gn_fuse;
       const int C1 = s1 >= 0 ? T(s1).C : 0;
       if (fuse && (C / 32) % 4 == 0 && T(s0).C % 4 == 0 && C1 % 4 == 0) {
         op.fin_ok = 1;
@@ -213,7 +213,7 @@ struct Walker {
     }
     const int yn = add_gn(x, -1, p + ".norm.weight", p + ".norm.bias", -1, 0);
     const double Tn_ = (double)T(x).H * T(x).W;
-    if (yn < 0 && !cfg.differentiable && attn_fused_eligible(dtype, T(x).H * T(x).W, C, heads, ch)) {
+    if (yn < 0 && !cfg.differentiable && attn_fused_eligible(dtype, T(x).H * T(x).W, C, heads, ch, &net->knobs)) {
       // norm-apply + qkv 1x1 + attention in one kernel (attn_fused.hip): the [T, 3C] qkv tensor never exists
       PlanOp op; op.kind = OP_ATTN_FUSED; op.src0 = x; op.heads = heads; op.ch = ch; op.Cout = 3 * C;
       op.w_off = put_conv(p + ".qkv.weight", 3 * C, C, 1, true);
@@ -415,6 +415,8 @@ static int run_walker(const mi355_unet_config& cfg, const float* const* host, mi
   if (int rc = unet_enumerate_params(cfg, w.params)) return rc;
   for (size_t i = 0; i < w.params.size(); ++i) w.pidx[w.params[i].name] = (int)i;
   net->cfg = cfg;
+  net->knobs = cfg.debug ? *cfg.debug : mi355_default_debug();
+  net->cfg.debug = nullptr;
   if (w.walk() != 0 || !w.err.empty()) { mi355_set_error("unet plan: " + w.err); return -4; }
   return 0;
 }
@@ -438,12 +440,29 @@ int unet_build(const mi355_unet_config& cfg, const float* const* params_host, in
     if (e == hipSuccess) e = hipStreamSynchronize(stream);  // blob is a temporary: creation is a one-off, not a hot path
     if (e != hipSuccess) { mi355_set_error(std::string("unet_create: weight upload: ") + hipGetErrorString(e)); rc = -3; }
   }
+  if (rc == 0) {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&net->err_host), 64, hipHostMallocMapped);
+    if (e == hipSuccess) { *net->err_host = 0u; e = hipHostGetDevicePointer(reinterpret_cast<void**>(&net->err_dev), net->err_host, 0); }
+    if (e != hipSuccess) { (void)hipGetLastError(); mi355_set_error(std::string("unet_create: pinned error word: ") + hipGetErrorString(e)); rc = -3; }
+  }
   if (rc) { delete net; return rc; }
   net->params = w.params;
   net->dev_weights = reinterpret_cast<char*>(dev_weights);
   net->dev_weights_bytes = (int64_t)w.cursor;
   *out = net;
   return 0;
+}
+
+mi355_unet::~mi355_unet() { if (err_host) (void)hipHostFree(err_host); }
+
+int unet_status(const mi355_unet* net, int clear) {
+  if (!net || !net->err_host) return 0;
+  const uint32_t v = *reinterpret_cast<volatile uint32_t*>(net->err_host);
+  if (clear) *reinterpret_cast<volatile uint32_t*>(net->err_host) = 0u;
+  if (v == 0u) return 0;
+  mi355_set_error("a launch of this handle gave up a bounded counter wait of the persistent conv (hand-over stalled): its output is invalid"
+                  " [error word " + std::to_string(v) + "]");
+  return MI355_ERR_TIMEOUT;
 }
 
 WsLayout unet_ws_layout(const mi355_unet* net, int B) {
@@ -492,6 +511,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
                  void* workspace, int64_t workspace_bytes, hipStream_t stream, const UnetRun& run) {
   MI355_REQUIRE(net && x && t && out && workspace, -1, "unet_forward: null argument");
   MI355_REQUIRE(B > 0, -1, "unet_forward: batch must be positive");
+  if (int rc = unet_status(net, 0)) return rc;   // an earlier launch of this handle gave up a counter wait
   MI355_REQUIRE(Cx + (cond ? Cc : 0) == net->cfg.in_channels, -2, "unet_forward: x/cond channels do not add up to in_channels");
   const WsLayout l = ws_layout(net, B);
   MI355_REQUIRE((int64_t)l.total <= workspace_bytes, -2, "unet_forward: workspace too small");
@@ -520,7 +540,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
   { mi355_op_profile r{}; r.kind = MI355_OP_PRELUDE; mark(r); }
   // the conv a GroupNorm pass feeds is the next op of the plan: the pass warms the L2s with its weights (common.h l2_warm_wave)
-  static const int warm_mask = getenv("MI355_L2_WARM") ? atoi(getenv("MI355_L2_WARM")) : 1;   // 1 = statistics / apply passes, 2 = finalize passes (measured: no gain, off)
+  const int warm_mask = net->knobs.l2_warm;   // 1 = statistics / apply passes, 2 = finalize passes (measured: no gain, off)
   auto warm_next = [&](const PlanOp& op, const void*& wp, uint32_t& wb, int bit) {
     const size_t oi = (size_t)(&op - net->ops.data());
     if (!(warm_mask & bit) || oi + 1 >= net->ops.size() || net->ops[oi + 1].kind != OP_CONV) return;
@@ -569,6 +589,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       if (op.emb_off >= 0) { c.emb = embp + op.emb_off; c.emb_stride = estride; }
       if (op.res >= 0) { c.res = TP(op.res); c.res_mode = op.res_mode; }
       c.out_mode = op.out_mode;
+      c.knobs = &net->knobs; c.err = net->err_dev;
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
       int slots = 0;
       if (op.dst >= 0 && net->tensors[op.dst].stats_cap) { c.gn_stats = SP(op.dst); c.gn_slots_cap = net->tensors[op.dst].stats_cap; }

@@ -214,11 +214,12 @@ class UNetModel(nn.Module):
                tuple(p.data_ptr() for p in params))
         if differentiable:
             if self._dengine is None or key != self._dengine_key:
-                self._dengine = UNetEngine(self._cfg_kwargs(), self.state_dict(), device, self.precision, differentiable=True)
+                self._dengine = UNetEngine(self._cfg_kwargs(), self.state_dict(), device, self.precision, differentiable=True,
+                                           debug=getattr(self, "debug", None))
                 self._dengine_key = key
             return self._dengine
         if self._engine is None or key != self._engine_key:
-            self._engine = UNetEngine(self._cfg_kwargs(), self.state_dict(), device, self.precision)
+            self._engine = UNetEngine(self._cfg_kwargs(), self.state_dict(), device, self.precision, debug=getattr(self, "debug", None))
             self._engine_key = key
         return self._engine
 

@@ -22,6 +22,34 @@ class MI355BackendError(RuntimeError):
     pass
 
 
+class DebugConfigC(C.Structure):
+    """mi355_debug_config (include/mi355_sampler.h): diagnostic switches, copied into a handle at creation / passed to the test ops."""
+    _fields_ = [("conv_ws", C.c_int32), ("conv_small", C.c_int32), ("conv_min_wgs", C.c_int32), ("conv_stagger", C.c_int32),
+                ("conv_ablate", C.c_int32), ("conv_spin_limit", C.c_int32), ("conv_time_reps", C.c_int32), ("gn_apply_max_hw", C.c_int32),
+                ("gn_fuse", C.c_int32), ("l2_warm", C.c_int32), ("attn_fused", C.c_int32), ("gn_pass", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+# experiment scripts (tools/*.sh) set these; the LIBRARY reads no environment variable - the Python binding turns them into the struct
+_DEBUG_ENV = {"MI355_CONV_WS": "conv_ws", "MI355_CONV_SMALL": "conv_small", "MI355_CONV_MINWG": "conv_min_wgs", "MI355_CONV_STAGGER": "conv_stagger",
+              "MI355_CONV_ABLATE": "conv_ablate", "MI355_CONV_SPIN": "conv_spin_limit", "MI355_CONV_TIME": "conv_time_reps",
+              "MI355_GN_APPLY_MAXHW": "gn_apply_max_hw", "MI355_GN_FUSE": "gn_fuse", "MI355_L2_WARM": "l2_warm", "MI355_ATTN_FUSE": "attn_fused",
+              "MI355_GN_PASS": "gn_pass"}
+
+
+def debug_config(**overrides) -> "DebugConfigC":
+    """Defaults from the library, then MI355_* environment variables (experiments), then keyword overrides (tests)."""
+    d = DebugConfigC()
+    lib().mi355_debug_defaults(C.byref(d))
+    for env, field in _DEBUG_ENV.items():
+        if os.environ.get(env, "") != "":
+            setattr(d, field, int(os.environ[env]))
+    for k, v in overrides.items():
+        if k not in dict((f[0], 1) for f in DebugConfigC._fields_):
+            raise KeyError(k)
+        setattr(d, k, int(v))
+    return d
+
+
 class UNetConfigC(C.Structure):
     _fields_ = [
         ("image_size", C.c_int32), ("in_channels", C.c_int32), ("model_channels", C.c_int32),
@@ -30,6 +58,7 @@ class UNetConfigC(C.Structure):
         ("conv_resample", C.c_int32), ("num_heads", C.c_int32), ("num_head_channels", C.c_int32),
         ("num_heads_upsample", C.c_int32), ("use_scale_shift_norm", C.c_int32), ("resblock_updown", C.c_int32),
         ("use_new_attention_order", C.c_int32), ("dtype", C.c_int32), ("differentiable", C.c_int32),
+        ("debug", C.POINTER(DebugConfigC)),
     ]
 
 
@@ -66,6 +95,8 @@ _VP, _I, _I64, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "mi355_version": (_I, []),
     "mi355_last_error": (C.c_char_p, []),
+    "mi355_debug_defaults": (None, [C.POINTER(DebugConfigC)]),
+    "mi355_unet_status": (_I, [_VP, _I]),
     "mi355_unet_param_count": (_I, [C.POINTER(UNetConfigC)]),
     "mi355_unet_param_info": (_I, [C.POINTER(UNetConfigC), _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "mi355_unet_weight_bytes": (_I64, [C.POINTER(UNetConfigC)]),
@@ -103,7 +134,8 @@ SIGNATURES = {
     "mi355_rk_sqnorm": (_I, [_VP, _VP, _VP, _VP, _F, _F, _I64, _VP, _VP]),
     "mi355_rk_interp": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _I64, _VP]),
     "mi355_op_workspace_bytes": (_I64, [_I, _I, _I]),
-    "mi355_conv2d": (_I, [_VP, _VP, _I, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _I, _VP, _I64, _VP]),
+    "mi355_conv2d": (_I, [_VP, _VP, _I, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _I, C.POINTER(DebugConfigC), _VP,
+                          _I64, _VP]),
     "mi355_qkv_attention": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I64, _VP]),
 }
 
@@ -157,8 +189,10 @@ def check(rc: int, what: str = ""):
 
 def make_config(*, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_ds, channel_mult,
                 conv_resample=True, num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
-                resblock_updown=False, use_new_attention_order=False, dtype=MI355_BF16, differentiable=False) -> UNetConfigC:
+                resblock_updown=False, use_new_attention_order=False, dtype=MI355_BF16, differentiable=False, debug=None) -> UNetConfigC:
     c = UNetConfigC()
+    c._debug_keepalive = debug if debug is not None else debug_config()   # the struct must outlive the pointer (read at creation)
+    c.debug = C.pointer(c._debug_keepalive)
     c.image_size, c.in_channels, c.model_channels, c.out_channels = image_size, in_channels, model_channels, out_channels
     c.num_res_blocks = num_res_blocks
     attention_ds = list(attention_ds)

@@ -30,7 +30,8 @@ def param_inventory(cfg: _lib.UNetConfigC):
 
 
 class UNetEngine:
-    def __init__(self, cfg_kwargs: dict, state_dict: Dict[str, torch.Tensor], device, precision: str = "bf16", differentiable: bool = False):
+    def __init__(self, cfg_kwargs: dict, state_dict: Dict[str, torch.Tensor], device, precision: str = "bf16", differentiable: bool = False,
+                 debug=None):
         if precision not in _PREC:
             raise ValueError(f"precision must be one of {sorted(_PREC)}")
         self.device = torch.device(device)
@@ -38,7 +39,7 @@ class UNetEngine:
             raise MI355BackendError(f"UNetEngine needs an MI355X device, got {self.device} (no CPU fallback)")
         self.precision = precision
         self.differentiable = bool(differentiable)
-        self.cfg = _lib.make_config(dtype=_PREC[precision], differentiable=differentiable, **cfg_kwargs)
+        self.cfg = _lib.make_config(dtype=_PREC[precision], differentiable=differentiable, debug=debug, **cfg_kwargs)
         self.L = _lib.lib()
         inv = param_inventory(self.cfg)
         host = []
@@ -73,6 +74,11 @@ class UNetEngine:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def check(self, clear: bool = True):
+        """Raise MI355BackendError if a launch of this engine gave up a bounded counter wait (mi355_unet_status).  Synchronise first to
+        cover the launches already queued; every engine call also checks the flag on entry."""
+        check(self.L.mi355_unet_status(self.handle, int(clear)), "mi355_unet_status")
 
     def workspace(self, batch: int):
         need = check(self.L.mi355_unet_workspace_bytes(self.handle, batch), "mi355_unet_workspace_bytes")

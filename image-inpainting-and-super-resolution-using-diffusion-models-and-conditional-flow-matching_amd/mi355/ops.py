@@ -198,7 +198,7 @@ class Ops:
 
     # --- parity-test ops on NCHW fp32 tensors (pack -> MFMA kernel -> unpack) ---
     def conv2d(self, x, weight, bias=None, stride=1, resample=0, gn=None, gn_silu=False, dtype=_lib.MI355_F32, x1=None, emb=None,
-               res=None, res_mode=1):
+               res=None, res_mode=1, debug=None):
         """weight/bias: CPU fp32 tensors in the reference layout [Co,Ci(+Ci1),k,k]; gn = (gamma, beta) device tensors over the
         (concatenated) input channels; x1: second source of a channel concat; emb [B, Co]; res [B, Co, Hr, Wr] with res_mode 1
         (same size) or 2 (nearest x2 of a half-size tensor)."""
@@ -229,7 +229,8 @@ class Ops:
                              C.cast(b.data_ptr(), fp) if b is not None else None, _req(y, "y"), B, Cin, H, W, Co, k, stride, resample,
                              _req(gn[0], "gamma") if gn else None, _req(gn[1], "beta") if gn else None, int(gn_silu),
                              _req(emb, "emb") if emb is not None else None, _req(res, "res") if res is not None else None, int(res_mode),
-                             dtype, C.c_void_p(ws.data_ptr()), wsb, _stream()), "mi355_conv2d")
+                             dtype, C.byref(debug if debug is not None else _lib.debug_config()), C.c_void_p(ws.data_ptr()), wsb, _stream()),
+              "mi355_conv2d")
         return y
 
     def qkv_attention(self, qkv, heads, new_order=False, dtype=_lib.MI355_F32):

@@ -30,6 +30,7 @@ extern "C" {
 #define MI355_ERR_SHAPE (-2)
 #define MI355_ERR_HIP (-3)
 #define MI355_ERR_UNSUPPORTED (-4)
+#define MI355_ERR_TIMEOUT (-5) /* a kernel's bounded counter wait expired (see mi355_unet_status): results of that launch are invalid */
 
 /* compute type of the contraction path */
 #define MI355_F32 0  /* fp32 storage, exact f32 MFMA (v_mfma_f32_16x16x4_f32): tight-parity mode   */
@@ -37,6 +38,29 @@ extern "C" {
 
 int mi355_version(void);
 const char* mi355_last_error(void);
+
+/* ---- diagnostic switches -------------------------------------------------------------------------------------------------------
+ * Every kernel-path choice the library makes can be overridden here, for experiments and tests only; NULL (or a struct filled by
+ * mi355_debug_defaults) = the shipped behaviour.  The struct is COPIED into the handle at mi355_unet_create and passed per call to
+ * the test ops: the library reads no environment variable and keeps no process-global switch. */
+typedef struct mi355_debug_config {
+  int32_t conv_ws;         /* 1: 3x3 convs of the large levels run on the persistent warp-specialised kernel (conv_ws.inc.h); 0: plain tiles */
+  int32_t conv_small;      /* 1: 8x8 / 4x4 levels run on the LDS-resident-patch kernel (conv_small.inc.h) */
+  int32_t conv_min_wgs;    /* 512: the plain kernel takes the largest tile that still yields this many workgroups */
+  int32_t conv_stagger;    /* 0: plain kernel: start delay of the odd workgroup slot; persistent kernel: wave priorities (consumer | loader << 2) */
+  int32_t conv_ablate;     /* 0: timing experiments, results become wrong: 1 no output stores, 2 no prologue math, 32 the loaders never
+                            *    publish kernel row 5 (the consumers' counter wait then expires: exercises MI355_ERR_TIMEOUT) */
+  int32_t conv_spin_limit; /* 4194304: polls of an LDS counter before a wait of the persistent kernel gives up and flags the launch */
+  int32_t conv_time_reps;  /* 0: mi355_conv2d only: re-launch the conv this many times between two events and print the average */
+  int32_t gn_apply_max_hw; /* 64: GroupNorm sites on images up to this many pixels write silu(a x + b) themselves (prologue-free conv) */
+  int32_t gn_fuse;         /* 1: GroupNorm statistics come from partial sums in the producing convs' epilogues where possible */
+  int32_t l2_warm;         /* 1: bit 0: statistics / apply passes touch the next conv's weights; bit 1: finalize passes too */
+  int32_t attn_fused;      /* 1: GroupNorm-apply + qkv + attention in one kernel where the shape allows */
+  int32_t gn_pass;         /* 1: out_layers GroupNorm sites whose ResBlock has a 1x1 skip conv run a finalize + apply pass so that the skip
+                            *    conv can be folded into the (then prologue-free) second conv; 0: never; 2: every large-image site */
+  int32_t reserved[4];
+} mi355_debug_config;
+void mi355_debug_defaults(mi355_debug_config* out);
 
 /* ---- U-Net (AD/image_diffusion/unet.py:490-728 UNetModel; == torchcfm UNetModelWrapper) ---------- */
 
@@ -59,6 +83,7 @@ typedef struct mi355_unet_config {
   int32_t use_new_attention_order;
   int32_t dtype; /* MI355_F32 | MI355_BF16 */
   int32_t differentiable; /* 1: keep what mi355_unet_vjp needs (per-site GroupNorm statistics, the qkv tensors, transposed weights) */
+  const mi355_debug_config* debug; /* NULL = defaults; copied at mi355_unet_create */
 } mi355_unet_config;
 
 typedef struct mi355_unet mi355_unet; /* opaque */
@@ -78,6 +103,12 @@ int mi355_unet_create(const mi355_unet_config* cfg, const float* const* params_h
 void mi355_unet_destroy(mi355_unet* net);
 
 int64_t mi355_unet_workspace_bytes(const mi355_unet* net, int batch);
+
+/* 0, or MI355_ERR_TIMEOUT when a launch of this handle gave up a bounded counter wait (the persistent conv never hangs: a stalled
+ * hand-over ends after conv_spin_limit polls, the launch's output is then invalid).  The flag is one word of pinned host memory
+ * the kernels write through; it is also checked at the start of every call that takes the handle, so a failure is reported by the
+ * next call at the latest - synchronise the stream first to learn about the launches already queued.  `clear` resets it. */
+int mi355_unet_status(mi355_unet* net, int clear);
 
 /* UNetModel.forward(x, timesteps) (unet.py:708-728).  x: [B, Cx, H, W]; cond: NULL or [B, Cc, H, W]
  * with Cx + Cc == in_channels (the Amortized sampler's channel concat, AD/image_diffusion/sampling.py:39,
@@ -281,11 +312,12 @@ int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw);
  * pointers or NULL), i.e. the ResBlock in_layers / out_layers (unet.py:283-286,306-311).
  * Optional fused epilogue: + emb[B, Co] (ResBlock emb_layers, unet.py:349) and + res (NULL or [B, Co, Hr, Wr]; res_mode 1:
  * Hr = Ho (skip + h, unet.py:351,401), 2: nearest x2 of a half-size tensor (ResBlock(up=True), unet.py:332-334)).
- * Synchronises the stream (test op: the packed weights are staged from a temporary host buffer). */
+ * Synchronises the stream (test op: the packed weights are staged from a temporary host buffer); returns MI355_ERR_TIMEOUT if the
+ * launch flagged an expired counter wait.  debug: NULL = defaults. */
 int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
                  int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
-                 const float* emb, const float* res, int res_mode, int dtype, void* workspace, int64_t workspace_bytes,
-                 void* stream);
+                 const float* emb, const float* res, int res_mode, int dtype, const mi355_debug_config* debug, void* workspace,
+                 int64_t workspace_bytes, void* stream);
 /* QKVAttentionLegacy / QKVAttention (unet.py:424-487): qkv [B, 3*H*ch, T] -> out [B, H*ch, T] */
 int mi355_qkv_attention(const float* qkv, float* out, int batch, int heads, int head_channels, int length, int new_order,
                         int dtype, void* workspace, int64_t workspace_bytes, void* stream);

@@ -247,3 +247,27 @@ def test_forward_with_host_scalar_time_matches_tensor_time():
         b = eng.forward(x, torch.full((B,), 0.37, device=DEV))
         # one embedding row broadcast vs B identical rows: the small linear kernels sum in a batch-size-dependent order (fp32 rounding)
         torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-6)
+
+
+def test_persistent_conv_spin_limit_is_reported_not_hung(ops):
+    """conv3x3_ws_kernel bounds every counter poll (conv_ws.inc.h): when the limit expires the launch must end AND say so.  Forced
+    here through the diagnostic switches (conv_ablate bit 32: the loaders never publish kernel row 5; a tiny spin limit): the test op
+    returns MI355_ERR_TIMEOUT with a message instead of rc 0 with corrupted activations; the same shape with default switches is
+    correct right afterwards (the error word is per call)."""
+    from mi355._lib import MI355BackendError, debug_config
+
+    x = randn(811, 64, 128, 32, 32)
+    sd = synth_state_dict({"weight": (128, 128, 3, 3), "bias": (128,)}, 812)
+    want = F.conv2d(x, sd["weight"], sd["bias"], padding=1)
+    for gn in (None, True):     # both loader variants: DMA-only (no prologue) and register-staged (GN + SiLU prologue)
+        gnp = None
+        ref = want
+        if gn:
+            gsd = synth_state_dict({"g": (128,), "b": (128,)}, 813)
+            gnp = (gsd["g"].to(DEV), gsd["b"].to(DEV))
+            ref = F.conv2d(F.silu(unet_ref.group_norm32(x, gsd["g"], gsd["b"])), sd["weight"], sd["bias"], padding=1)
+        with pytest.raises(MI355BackendError, match="counter wait"):
+            ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], gn=gnp, gn_silu=bool(gn), dtype=_lib.MI355_BF16,
+                       debug=debug_config(conv_ablate=32, conv_spin_limit=64))
+        got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], gn=gnp, gn_silu=bool(gn), dtype=_lib.MI355_BF16).cpu()
+        torch.testing.assert_close(got, ref, rtol=3e-2, atol=3e-2)

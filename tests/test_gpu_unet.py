@@ -397,3 +397,51 @@ def test_utils_cifar_generate_samples_writes_grid(tmp_path):
     assert net.training
     img = Image.open(tmp_path / "ema_generated_FM_images_step_123.png")
     assert img.size == (8 * 34 + 2, 8 * 34 + 2) and img.mode == "RGB"
+
+
+def test_engine_error_word_and_diagnostic_switches():
+    """(1) The handle's error word: a forced counter-wait expiry inside a whole forward surfaces as MI355BackendError from
+    engine.check() after a synchronise, and from the NEXT engine call if nobody asked.  (2) Every kernel-path switch of
+    mi355_debug_config (they used to be environment variables nobody tested): plain tiles instead of the persistent / small-level
+    kernels, statistics passes instead of epilogue partial sums, unfused attention, no apply passes - the same forward to fp32
+    rounding (fp32 mode; summation orders differ between the paths)."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import MI355BackendError, debug_config
+
+    kw = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(2,),
+              channel_mult=(1, 2, 2), num_heads=4, num_head_channels=64)
+    sd = None
+    B = 72      # 32x32: 288 tiles of 16x16 >= 256 CUs -> the persistent kernel runs with default switches
+    x = randn(4100, B, 3, 32, 32).to(DEV)
+    t = torch.linspace(0, 1, B).to(DEV)
+
+    def run(precision="fp32", **knobs):
+        nonlocal sd
+        net = UNetModel(precision=precision, **kw)
+        if sd is None:
+            sd = synth_state_dict(param_shapes(net), 4101)
+        net.load_state_dict(sd)
+        net.debug = debug_config(**knobs)
+        net.to(DEV)
+        return net, net.engine(DEV)
+
+    net, eng = run("bf16", conv_ablate=32, conv_spin_limit=64)
+    eng.forward(x, t)
+    torch.cuda.synchronize()
+    with pytest.raises(MI355BackendError, match="counter wait"):
+        eng.check(clear=False)
+    with pytest.raises(MI355BackendError, match="counter wait"):     # still set: the next call refuses to build on invalid activations
+        eng.forward(x, t)
+    with pytest.raises(MI355BackendError):
+        eng.check(clear=True)
+    eng.check()                                                       # cleared
+    _, e0 = run()
+    base = e0.forward(x, t).cpu()
+    torch.cuda.synchronize(); e0.check()
+    variants = [dict(conv_ws=0), dict(conv_small=0), dict(conv_ws=0, conv_small=0, conv_min_wgs=100000), dict(gn_fuse=0), dict(attn_fused=0),
+                dict(gn_apply_max_hw=0), dict(gn_apply_max_hw=4096), dict(l2_warm=0), dict(l2_warm=3), dict(conv_stagger=1, conv_ws=0)]
+    for kn in variants:
+        _, e = run(**kn)
+        y = e.forward(x, t).cpu()
+        torch.cuda.synchronize(); e.check()
+        torch.testing.assert_close(y, base, rtol=2e-4, atol=5e-5, msg=lambda m, kn=kn: f"{kn}: {m}")
