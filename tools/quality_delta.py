@@ -10,7 +10,14 @@ cannot produce 10 k).  Reports
     (b) a scale reference = fp32 samples with 25 instead of 50 Euler steps (a real change of the sampler).
 True FID needs cleanfid's downloaded Inception weights + CIFAR statistics (cifar10/compute_fid.py:92-100): unavailable offline.
 
-    python tools/quality_delta.py [--n 10240] [--out gpurun_out/r2_quality_delta.json]
+Round 3 (task 6): with N(0, 0.02^2) synthetic weights the learned-field stand-in barely bends the trajectories (50 vs
+25 Euler steps differed LESS than bf16 vs fp32), so the proxy could not tell samplers apart.  `--gain auto` (the default now) rescales
+the last conv (out.2) so that the field's rms at t = 0 is 1: |x1 - x0| becomes comparable to |x0|, the deep net's x-dependence bends
+the paths, and a change of the step count becomes visible.  Reported side by side, all from the same x0: bf16 vs fp32, 50 vs 25
+steps, 50 vs 49 steps, plus the disjoint-x0 floor; the claim to check is "bf16 moves the sample distribution less than dropping
+ONE Euler step does".
+
+    python tools/quality_delta.py [--n 10240] [--gain auto|1.0|<float>] [--out gpurun_out/r3_quality_delta.json]
 """
 import argparse
 import json
@@ -32,7 +39,8 @@ def main():
     ap.add_argument("--n", type=int, default=10240)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--nfe", type=int, default=50)
-    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r2_quality_delta.json"))
+    ap.add_argument("--gain", default="auto", help="multiplier of out.2 (weight and bias); auto = 1 / rms of the field at t = 0")
+    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r3_quality_delta.json"))
     a = ap.parse_args()
 
     import evaluation
@@ -42,20 +50,39 @@ def main():
 
     dev = torch.device("cuda:0")
     net = build_model(128, dev, precision="bf16")
-    net.load_state_dict(synth_state_dict(param_shapes(net), 1234))
+    sd = synth_state_dict(param_shapes(net), 1234)
+    net.load_state_dict(sd)
     nb = (a.n + a.batch - 1) // a.batch
+    # field gain: rms of v(x0, t = 0) with the plain synthetic weights -> scale out.2 so that it becomes 1
+    g0 = torch.Generator(device=dev).manual_seed(0)
+    xprobe = torch.randn(a.batch, 3, 32, 32, device=dev, generator=g0)
+    net.set_precision("fp32")
+    v_rms_plain = float(net.engine(dev).forward(xprobe, 0.0).pow(2).mean().sqrt())
+    gain = (1.0 / v_rms_plain) if a.gain == "auto" else float(a.gain)
+    sd = dict(sd)
+    sd["out.2.weight"] = sd["out.2.weight"] * gain
+    sd["out.2.bias"] = sd["out.2.bias"] * gain
+    net.load_state_dict(sd)
+    v_rms = float(net.engine(dev).forward(xprobe, 0.0).pow(2).mean().sqrt())
+    print(f"field rms at t=0: {v_rms_plain:.4f} with N(0, 0.02^2) weights -> {v_rms:.4f} with out.2 x {gain:.3f}", flush=True)
+
+    moves = {}
 
     def sample_set(precision, seed0, nfe):
         net.set_precision(precision)
         eng = net.engine(dev)
         ts = torch.linspace(0, 1, nfe + 1).tolist()
         xs, u8s = [], []
+        move = []
         t0 = time.perf_counter()
         for k in range(nb):
             g = torch.Generator(device=dev).manual_seed(seed0 + k)
             x = torch.randn(a.batch, 3, 32, 32, device=dev, generator=g)
+            x0 = x.clone()
             _, _, u8 = eng.cfm_euler(x, ts, want_u8=True)
+            move.append(float(((x - x0).pow(2).sum() / x0.pow(2).sum()).sqrt()))
             xs.append(x.cpu()); u8s.append(u8.cpu())
+        moves[(precision, seed0, nfe)] = sum(move) / len(move)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"{precision} nfe {nfe} seeds {seed0}..: {nb * a.batch} samples in {dt:.1f} s ({nb * a.batch / dt:.0f} img/s)", flush=True)
@@ -64,13 +91,19 @@ def main():
     x16, u16 = sample_set("bf16", 0, a.nfe)
     x32, u32 = sample_set("fp32", 0, a.nfe)
     _, u32b = sample_set("fp32", 100000, a.nfe)          # disjoint x0: same-distribution floor
-    _, u32h = sample_set("fp32", 0, a.nfe // 2)          # half the Euler steps: a real sampler change, for scale
+    x32h, u32h = sample_set("fp32", 0, a.nfe // 2)       # half the Euler steps: a real sampler change, for scale
+    x32m, u32m = sample_set("fp32", 0, a.nfe - 1)        # ONE Euler step fewer: the smallest change of the sampler one can make
     err = (x16 - x32).abs()
     per_sample_rms = (x16 - x32).pow(2).mean(dim=(1, 2, 3)).sqrt()
     code = (u16.int() - u32.int()).abs()
-    f16, f32, f32b, f32h = (evaluation.random_conv_features(u, seed=0) for u in (u16, u32, u32b, u32h))
+    f16, f32, f32b, f32h, f32m = (evaluation.random_conv_features(u, seed=0) for u in (u16, u32, u32b, u32h, u32m))
+    rms = lambda d: float(d.pow(2).mean().sqrt())
     res = {
         "workload": "cifar10_cfm_euler50 (BASELINE configs[1] net, synthetic seeded weights)", "n_samples": int(x16.shape[0]), "nfe": a.nfe,
+        "field": {"out2_gain": gain, "rms_v_t0_plain_weights": v_rms_plain, "rms_v_t0": v_rms,
+                  "relative_move_|x1-x0|/|x0|_fp32": moves[("fp32", 0, a.nfe)]},
+        "per_sample_rms_same_x0": {"bf16_vs_fp32": rms(x16 - x32), f"{a.nfe}_vs_{a.nfe - 1}_steps": rms(x32 - x32m),
+                                   f"{a.nfe}_vs_{a.nfe // 2}_steps": rms(x32 - x32h)},
         "per_sample_bf16_vs_fp32": {
             "max_abs": float(err.max()), "rms": float((x16 - x32).pow(2).mean().sqrt()), "state_abs_max": float(x32.abs().max()),
             "worst_sample_rms": float(per_sample_rms.max()), "median_sample_rms": float(per_sample_rms.median()),
@@ -83,10 +116,12 @@ def main():
             "floor_fp32_vs_fp32_disjoint_x0": evaluation.frechet_distance(f32, f32b),
             "bf16_vs_fp32_disjoint_x0": evaluation.frechet_distance(f16, f32b),
             "scale_fp32_50step_vs_25step_same_x0": evaluation.frechet_distance(f32, f32h),
+            "scale_fp32_50step_vs_49step_same_x0": evaluation.frechet_distance(f32, f32m),
         },
     }
     fp = res["frechet_proxy"]
     fp["fid_proxy_delta"] = fp["bf16_vs_fp32_disjoint_x0"] - fp["floor_fp32_vs_fp32_disjoint_x0"]
+    fp["bf16_moves_the_distribution_less_than_one_euler_step"] = bool(fp["bf16_vs_fp32_same_x0"] < fp["scale_fp32_50step_vs_49step_same_x0"])
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
     print(json.dumps(res))
