@@ -267,7 +267,7 @@ def main():
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
     achieved = dfl / (dms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    for pmc_name in ("r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
+    for pmc_name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
         pmc_file = os.path.join(REPO, "profiles", pmc_name)
         if os.path.exists(pmc_file) and a.precision == "bf16" and name == DEFAULT and B == 256:
             ent = json.load(open(pmc_file)).get("kernels", {}).get("conv3x3_ws_kernel")

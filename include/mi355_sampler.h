@@ -56,9 +56,7 @@ typedef struct mi355_debug_config {
   int32_t gn_fuse;         /* 1: GroupNorm statistics come from partial sums in the producing convs' epilogues where possible */
   int32_t l2_warm;         /* 1: bit 0: statistics / apply passes touch the next conv's weights; bit 1: finalize passes too */
   int32_t attn_fused;      /* 1: GroupNorm-apply + qkv + attention in one kernel where the shape allows */
-  int32_t gn_pass;         /* 1: out_layers GroupNorm sites whose ResBlock has a 1x1 skip conv run a finalize + apply pass so that the skip
-                            *    conv can be folded into the (then prologue-free) second conv; 0: never; 2: every large-image site */
-  int32_t reserved[4];
+  int32_t reserved[5];
 } mi355_debug_config;
 void mi355_debug_defaults(mi355_debug_config* out);
 
