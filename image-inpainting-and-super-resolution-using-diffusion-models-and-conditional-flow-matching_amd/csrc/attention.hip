@@ -29,8 +29,15 @@ struct AttnKArgs {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Register budget: with a 512-register budget (one workgroup per CU) the compiler puts the MFMA accumulators into AccVGPRs, and the
+// softmax / rescale between the two GEMMs then costs a v_accvgpr_read or _write per accumulator register and key tile (192 of them
+// beside 32 MFMAs at 64 channels).  Promising two workgroups per CU caps the budget at 256 = the VGPR form of the MFMAs, no copies;
+// the head sizes whose accumulators need more than that keep the full budget.
+template <typename T, int CH, int QB>
+constexpr int attn_min_blocks() { return (sizeof(T) == 2 ? CH * QB <= 192 : CH <= 96) ? 2 : 1; }
+
 template <typename T, int CH, int QB, int KT, int NBUF>
-__global__ void __launch_bounds__(256) attention_kernel(AttnKArgs p) {
+__global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention_kernel(AttnKArgs p) {
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK, SZ = sizeof(T);
   constexpr bool BF = E::DTYPE == 1;
@@ -125,18 +132,22 @@ __global__ void __launch_bounds__(256) attention_kernel(AttnKArgs p) {
       }
     // ---- online softmax over keys (column = query = lane&15; rows spread over regs and lane>>4), in the log2 domain:
     //      p = exp2(s * c2 - m2) with c2 = ch^-1/2 * log2(e) folded into one FMA per element (max, fma, exp2, add) ----
+    if ((kt + 1) * KT > p.T) {              // only a ragged last tile has keys to mask (wave-uniform)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * KT + mi * 16 + lq * 4 + r >= p.T) sacc[qb][mi][r] = -INFINITY;
+    }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float mx = -INFINITY;
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * KT + mi * 16 + lq * 4 + r;
-          const float v = key < p.T ? sacc[qb][mi][r] : -INFINITY;
-          sacc[qb][mi][r] = v;
-          mx = fmaxf(mx, v);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qb][mi][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run[qb], mx * c2);
@@ -152,10 +163,12 @@ __global__ void __launch_bounds__(256) attention_kernel(AttnKArgs p) {
         }
       l_run[qb] = l_run[qb] * alpha + psum;
       m_run[qb] = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // once the running maxima have settled no query of the wave rescales
 #pragma unroll
-      for (int ci = 0; ci < CI; ++ci)
+        for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[qb][ci][r] *= alpha;
+          for (int r = 0; r < 4; ++r) o[qb][ci][r] *= alpha;
+      }
     }
 
     // ---- O^T += V^T P^T ----

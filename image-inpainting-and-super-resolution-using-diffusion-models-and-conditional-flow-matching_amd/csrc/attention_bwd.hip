@@ -52,9 +52,14 @@ __device__ __forceinline__ u32x4 acc_frag(const f32x4& t0, const f32x4& t1) {
   }
 }
 
+// Register budget as in attention.hip (attn_min_blocks): two workgroups per CU = a 256-register budget = MFMAs in their VGPR form, no
+// v_accvgpr copies around the softmax; the head sizes whose live set needs more keep the full budget.
+template <typename T, int CH> constexpr int bwd_q_min_blocks() { return (sizeof(T) == 2 ? CH <= 192 : CH <= 96) ? 2 : 1; }
+template <typename T, int CH> constexpr int bwd_kv_min_blocks() { return (sizeof(T) == 2 ? CH <= 128 : CH <= 64) ? 2 : 1; }
+
 // ---- dQ (+ L, D) ----------------------------------------------------------------------------------------------------------------
 template <typename T, int CH>
-__global__ void __launch_bounds__(256) attention_bwd_q_kernel(AttnBwdArgs p) {
+__global__ void __launch_bounds__(256, (bwd_q_min_blocks<T, CH>())) attention_bwd_q_kernel(AttnBwdArgs p) {
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK, SZ = sizeof(T);
   constexpr bool BF = E::DTYPE == 1;
@@ -191,7 +196,7 @@ __global__ void __launch_bounds__(256) attention_bwd_q_kernel(AttnBwdArgs p) {
 
 // ---- dK, dV -------------------------------------------------------------------------------------------------------------------------
 template <typename T, int CH>
-__global__ void __launch_bounds__(256) attention_bwd_kv_kernel(AttnBwdArgs p) {
+__global__ void __launch_bounds__(256, (bwd_kv_min_blocks<T, CH>())) attention_bwd_kv_kernel(AttnBwdArgs p) {
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK, SZ = sizeof(T);
   constexpr bool BF = E::DTYPE == 1;
