@@ -47,6 +47,12 @@ struct ConvKArgs {
   int stagger;                       // odd-slot workgroup start delay in units of s_sleep(127) (~8k cycles each)
   uint32_t* err;                     // error word (device-visible): bit 0 = a counter wait of the persistent kernel expired
   int spin_limit;                    // polls before such a wait gives up
+  // small-level kernel only (conv_small.inc.h): the GroupNorm site that reads this conv's output is applied in the epilogue - a wave
+  // holds whole images x 64 channels = whole groups, so act_out = silu?(GN(out)) needs no pass of its own; out itself is written
+  // only if somebody else reads it (act_raw); one touch of the NEXT conv's packed weights (the pass's L2 warm-up moves here too)
+  void* act_out; const float* act_gamma; const float* act_beta; const float* act_film; int act_film_stride; float act_eps;
+  int act_silu, act_raw;
+  const void* warm; uint32_t warm_bytes;
 };
 
 #ifdef CONV_STAMPS
@@ -702,8 +708,9 @@ ConvGeom conv_geometry(const ConvDesc& d) {
   return r;
 }
 
-int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
+int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* act_done) {
   if (gn_slots_used) *gn_slots_used = 0;
+  if (act_done) *act_done = 0;
   {
     const int r = conv1x1_try_launch(d, stream, gn_slots_used);
     if (r <= 0) return r;
@@ -718,7 +725,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   Geo g; compute_geo(d, g);
   MI355_REQUIRE(g.lds <= 160 * 1024, -4, "conv: LDS budget exceeded");
   MI355_REQUIRE(g.pit <= g.pit_t, -4, "conv: input patch too large for the staging loops");
-  ConvKArgs a;
+  ConvKArgs a{};
   a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = Cin / CH;
   a.N = d.N; a.Hs = d.Hs; a.Ws = d.Ws; a.Hc = g.Hc; a.Wc = g.Wc; a.Ho = g.Ho; a.Wo = g.Wo;
   a.mode = d.mode; a.pad = g.pad; a.stride = g.stride;
@@ -756,8 +763,15 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
     a.gn_stats = nullptr; a.gn_slots = 0;
   }
   {   // 8x8 / 4x4 levels: barrier-free K loop over an LDS-resident patch, weights straight into registers (conv_small.inc.h)
-    const int r = d.dtype == 0 ? launch_small<float>(a, K.conv_small, d.ks, stream) : launch_small<bf16>(a, K.conv_small, d.ks, stream);
+    if (d.act_out && act_done && K.gn_epilogue) {
+      a.act_out = d.act_out; a.act_gamma = d.act_gamma; a.act_beta = d.act_beta; a.act_film = d.act_film; a.act_film_stride = d.act_film_stride;
+      a.act_eps = d.act_eps; a.act_silu = d.act_silu; a.act_raw = d.act_raw;
+      a.warm = (K.l2_warm & 1) ? d.warm : nullptr; a.warm_bytes = a.warm ? d.warm_bytes : 0u;
+    }
+    const int r = d.dtype == 0 ? launch_small<float>(a, K.conv_small, d.ks, stream, act_done) : launch_small<bf16>(a, K.conv_small, d.ks, stream, act_done);
     if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
+    if (act_done) *act_done = 0;
+    a.act_out = nullptr; a.warm = nullptr; a.warm_bytes = 0;
     if (r < 0) return r;
   }
   {

@@ -197,35 +197,48 @@ __global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Arg
   f32x4 bias4[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) bias4[ni] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co_w + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-  auto epi = [&](auto mic) {
+  // final values of pixel tile mi (accumulator + bias + emb + residual), and where they go.  The loads (residual, emb) are issued for
+  // every tile of the wave first (final_issue) and consumed afterwards (final_o): whatever is issued in between - the weight touches
+  // of the fused-GroupNorm epilogue - then queues BEHIND them (a wave's loads return in order)
+  u32x4 rr_all[MI][NP2]; f32x4 ev_all[MI][NI]; uint32_t ovo_all[MI]; int n_all[MI];
+  auto final_issue = [&](auto mic) {
     constexpr int mi = decltype(mic)::value;
     const int m = mi * 16 + lr;
     const int tx = m & VWm, ty = (m >> p.lvw) & THm, gi = m >> (p.lvw + p.lth);
     const int n = n0 + gi;
+    n_all[mi] = n;
     const bool ok = n < p.N && ty < p.Ho && tx < p.Wo;
     const uint32_t opix = (uint32_t)((n * p.Ho + ty) * p.Wo + tx);
     const uint32_t ovo = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.obytes;
+    ovo_all[mi] = ovo;
     const uint32_t rvo = (ok && p.res_mode != RES_NONE) ? ovo : p.rbytes;
-    u32x4 rr[NP2];
     if (p.res_mode != RES_NONE) {
 #pragma unroll
-      for (int k = 0; k < NP2; ++k) rr[k] = buf_load16(rsr, rvo + k * PSTEP * ESZ, 0);
+      for (int k = 0; k < NP2; ++k) rr_all[mi][k] = buf_load16(rsr, rvo + k * PSTEP * ESZ, 0);
     }
+    if (p.emb) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) ev_all[mi][ni] = *reinterpret_cast<const f32x4*>(p.emb + (size_t)min(n, p.N - 1) * p.emb_stride + co_w + ni * 16);
+    }
+  };
+  auto final_o = [&](auto mic, f32x4 (&o)[NI], uint32_t& ovo, int& n) {
+    constexpr int mi = decltype(mic)::value;
+    ovo = ovo_all[mi]; n = n_all[mi];
+    const u32x4 (&rr)[NP2] = rr_all[mi];
     f32x4 ad[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       ad[ni] = bias4[ni];
       if (p.emb) {
-        const f32x4 ev = *reinterpret_cast<const f32x4*>(p.emb + (size_t)min(n, p.N - 1) * p.emb_stride + co_w + ni * 16);
+        const f32x4 ev = ev_all[mi][ni];
         ad[ni] = f32x4{ad[ni][0] + ev[0], ad[ni][1] + ev[1], ad[ni][2] + ev[2], ad[ni][3] + ev[3]};
       }
     }
     if constexpr (!PAIR) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        f32x4 o = f32x4{acc[mi][ni][0] + ad[ni][0], acc[mi][ni][1] + ad[ni][1], acc[mi][ni][2] + ad[ni][2], acc[mi][ni][3] + ad[ni][3]};
-        if (p.res_mode != RES_NONE) { const f32x4 t = __builtin_bit_cast(f32x4, rr[ni]); o = f32x4{o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]}; }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo + ni * 16 * ESZ, 0, 0);
+        o[ni] = f32x4{acc[mi][ni][0] + ad[ni][0], acc[mi][ni][1] + ad[ni][1], acc[mi][ni][2] + ad[ni][2], acc[mi][ni][3] + ad[ni][3]};
+        if (p.res_mode != RES_NONE) { const f32x4 t = __builtin_bit_cast(f32x4, rr[ni]); o[ni] = f32x4{o[ni][0] + t[0], o[ni][1] + t[1], o[ni][2] + t[2], o[ni][3] + t[3]}; }
       }
     } else {
 #pragma unroll
@@ -241,24 +254,157 @@ __global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Arg
             rb[2 * j] = __builtin_bit_cast(float, xb[j] << 16); rb[2 * j + 1] = __builtin_bit_cast(float, xb[j] & 0xffff0000u);
           }
         }
-        bf16x4 ta, tb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          ta[j] = (bf16)(acc[mi][2 * k][j] + ad[2 * k][j] + ra[j]);
-          tb[j] = (bf16)(acc[mi][2 * k + 1][j] + ad[2 * k + 1][j] + rb[j]);
+          o[2 * k][j] = acc[mi][2 * k][j] + ad[2 * k][j] + ra[j];
+          o[2 * k + 1][j] = acc[mi][2 * k + 1][j] + ad[2 * k + 1][j] + rb[j];
         }
-        const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
-        const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
-        const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo + k * PSTEP * ESZ, 0, 0);
       }
     }
   };
-  if constexpr (KSPLIT == 1) { epi(IC<0>()); epi(IC<1>()); epi(IC<2>()); epi(IC<3>()); }
-  else if constexpr (KSPLIT == 2) {
-    if (kk == 0) { epi(IC<0>()); epi(IC<1>()); } else { epi(IC<2>()); epi(IC<3>()); }
-  } else {
-    if (kk == 0) epi(IC<0>()); else if (kk == 1) epi(IC<1>()); else if (kk == 2) epi(IC<2>()); else epi(IC<3>());
+  auto store_vals = [&](const f32x4 (&o)[NI], const __amdgpu_buffer_rsrc_t& rs, uint32_t ovo) {
+    if constexpr (!PAIR) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[ni]), rs, ovo + ni * 16 * ESZ, 0, 0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP2; ++k) {
+        bf16x4 ta, tb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ta[j] = (bf16)o[2 * k][j]; tb[j] = (bf16)o[2 * k + 1][j]; }
+        const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+        const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
+        const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rs, ovo + k * PSTEP * ESZ, 0, 0);
+      }
+    }
+  };
+  auto for_mine = [&](auto f) {           // the pixel tiles this wave finishes
+    if constexpr (KSPLIT == 1) { f(IC<0>()); f(IC<1>()); f(IC<2>()); f(IC<3>()); }
+    else if constexpr (KSPLIT == 2) {
+      if (kk == 0) { f(IC<0>()); f(IC<1>()); } else { f(IC<2>()); f(IC<3>()); }
+    } else {
+      if (kk == 0) f(IC<0>()); else if (kk == 1) f(IC<1>()); else if (kk == 2) f(IC<2>()); else f(IC<3>());
+    }
+  };
+  // (arrays written and read under DIFFERENT runtime branches end up in scratch memory: with K-sharing waves a tile's loads and its
+  // arithmetic stay inside one branch)
+  constexpr bool W8 = NCHP == 16;
+  constexpr bool ACT_OK = !(W8 && KSPLIT > 1);   // an 8x8 image split over K-sharing waves has no wave-local statistics (the host never asks)
+  auto plain_tile = [&](auto mic) {
+    f32x4 o[NI]; uint32_t ovo; int n;
+    final_o(mic, o, ovo, n);
+    store_vals(o, rso, ovo);
+  };
+  if (!ACT_OK || p.act_out == nullptr) {
+    if constexpr (KSPLIT == 1) { for_mine(final_issue); for_mine(plain_tile); }
+    else for_mine([&](auto mic) { final_issue(mic); plain_tile(mic); });
+    return;
+  }
+  if constexpr (ACT_OK) {
+  // ---- epilogue with the consumer's GroupNorm (+ SiLU) applied: GroupNorm32 (AD/image_diffusion/nn.py:11-13,87-94) over the conv's
+  // final values, fp32 statistics; a wave holds whole images (8x8: its four pixel tiles are one image; 4x4: pixel tile mi is image
+  // mi) x 64 channels = whole groups (cpg = 4 / 8 / 16: a lane's quad, two or four lq rows), so the statistics are wave-local:
+  // a DPP row sum over the 16 pixels of a tile row + one or two shuffles.  FiLM as in gn_affine_kernel. ----
+  constexpr bool FAST = E::DTYPE == 1;
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(p.act_out, 0, (p.ablate & 1) ? 0u : p.obytes, 0x00020000);
+  const int cpg = p.Cout >> 5;
+  const float inv_cnt = 1.0f / ((float)cpg * (float)(p.Ho * p.Wo));
+  f32x4 gam[NI], bet[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    gam[ni] = *reinterpret_cast<const f32x4*>(p.act_gamma + co_w + ni * 16);
+    bet[ni] = *reinterpret_cast<const f32x4*>(p.act_beta + co_w + ni * 16);
+  }
+  auto group_sum = [&](float v) {
+    v = GnPartial<1>::row_sum(v);
+    if (cpg >= 8) v += __shfl_xor(v, 16);
+    if (cpg >= 16) v += __shfl_xor(v, 32);
+    return v;
+  };
+  // y = silu?(a o + b) for pixel tile values o of image n, statistics (s, q) = group sums of o and o^2
+  auto apply_store = [&](const f32x4 (&o)[NI], const float (&gs)[NI], const float (&gq)[NI], int n, uint32_t ovo) {
+    f32x4 y[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const float mean = gs[ni] * inv_cnt;
+      const float var = fmaxf(gq[ni] * inv_cnt - mean * mean, 0.f);
+      const float rstd = 1.0f / sqrtf(var + p.act_eps);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = rstd * gam[ni][j];
+        float b = bet[ni][j] - mean * a;
+        if (p.act_film) {
+          const float* fp = p.act_film + (size_t)min(n, p.N - 1) * p.act_film_stride + co_w + ni * 16 + j;
+          const float sc = 1.0f + fp[0], sh = fp[p.Cout];
+          a *= sc;
+          b = b * sc + sh;
+        }
+        const float v = a * o[ni][j] + b;
+        y[ni][j] = p.act_silu ? (FAST ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)) : v / (1.0f + expf(-v))) : v;
+      }
+    }
+    store_vals(y, rsa, ovo);
+  };
+  // Touch of the NEXT conv's packed weights (the pass that used to warm the L2s with them is gone; as common.h l2_warm_wave, spread
+  // over all waves: the workgroups of an XCD cover the range once).  A wave's loads return in order, so the cold touches go behind
+  // the last load the epilogue waits for, and their latency overlaps the normalisation; measured alternatives: before the epilogue's
+  // arithmetic (same), behind the first chunk's weights at the start of the kernel (the weight stream stalls: 2-4 us slower).
+  uint32_t wv[4] = {0u, 0u, 0u, 0u};
+  auto warm_issue = [&]() {
+    if (p.warm_bytes == 0) return;
+    const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+    const uint32_t rank = wg >> 3, per = (nwg + 7) >> 3, step = per * 256u * 128u;
+    uint32_t off = (rank * 256u + tid) * 128u;
+    const char* base = reinterpret_cast<const char*>(p.warm);
+#pragma unroll
+    for (int i = 0; i < 4; ++i, off += step) wv[i] = *reinterpret_cast<const uint32_t*>(base + (off < p.warm_bytes ? off : 0u));
+  };
+  if constexpr (W8) {                     // KSPLIT == 1: the wave's four pixel tiles are one image
+    for_mine(final_issue);
+    float ls[NI] = {0.f, 0.f, 0.f, 0.f}, lq2[NI] = {0.f, 0.f, 0.f, 0.f};
+    for_mine([&](auto mic) {
+      constexpr int mi = decltype(mic)::value;
+      f32x4 o[NI]; uint32_t ovo; int n;
+      final_o(mic, o, ovo, n);
+      if (p.act_raw) store_vals(o, rso, ovo);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        acc[mi][ni] = o[ni];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ls[ni] += o[ni][j]; lq2[ni] += o[ni][j] * o[ni][j]; }
+      }
+    });
+    warm_issue();
+    float gs[NI], gq[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { gs[ni] = group_sum(ls[ni]); gq[ni] = group_sum(lq2[ni]); }
+    for_mine([&](auto mic) {
+      constexpr int mi = decltype(mic)::value;
+      apply_store(acc[mi], gs, gq, n_all[mi], ovo_all[mi]);
+    });
+  } else {                                // pixel tile mi is image mi
+    bool warmed = false;
+    auto act_tile = [&](auto mic) {
+      f32x4 o[NI]; uint32_t ovo; int n;
+      final_o(mic, o, ovo, n);
+      if (p.act_raw) store_vals(o, rso, ovo);
+      if (!warmed) { warm_issue(); warmed = true; }
+      float gs[NI], gq[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1 += o[ni][j]; s2 += o[ni][j] * o[ni][j]; }
+        gs[ni] = group_sum(s1); gq[ni] = group_sum(s2);
+      }
+      apply_store(o, gs, gq, n, ovo);
+    };
+    if constexpr (KSPLIT == 1) { for_mine(final_issue); for_mine(act_tile); }
+    else for_mine([&](auto mic) { final_issue(mic); act_tile(mic); });
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wv[i]));   // the touches have landed before the wave ends
   }
 }
 
@@ -266,7 +412,7 @@ __global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Arg
 // levels normalise in a pass of their own), NHWC output with C_out % 128 == 0, residual at the output resolution or none.
 // 0 = launched, 1 = not eligible (the caller goes on to the plain kernel), < 0 = error
 template <typename T>
-int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s) {
+int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* act_done) {
   ConvKArgs a = a0;
   if (!enabled || ks != 3 || a.stride != 1 || a.out_mode != OUT_NHWC || a.pro_a) return 1;
   if (a.Ho != a.Wo || (a.Ho != 8 && a.Ho != 4) || a.Cout % 128 != 0) return 1;
@@ -297,6 +443,12 @@ int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s) {
   const size_t lds = std::max((size_t)g.chp * g.plane, (size_t)g.red_bytes);
   if (lds > 160 * 1024) return 1;
   a.gn_stats = nullptr; a.gn_slots = 0;
+  {   // GroupNorm of the output in the epilogue: whole images per wave (an 8x8 image split over K-sharing waves is not), 4 / 8 / 16 channels per group
+    const int cpg = a.Cout / 32;
+    const bool ok = a.act_out && a.Cout % 32 == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && (!w8 || ksplit == 1);
+    if (!ok) { a.act_out = nullptr; a.warm = nullptr; a.warm_bytes = 0; }
+    if (act_done) *act_done = ok ? 1 : 0;
+  }
   dim3 grid(tiles, a.Cout / (64 * nw));
   int rc = 0;
   auto go = [&](auto kern) {

@@ -38,6 +38,12 @@ struct ConvDesc {
   void* dbg = nullptr;                      // diagnostic builds only (-DCONV_STAMPS): 9 x u64 phase-cycle sums
   const mi355_debug_config* knobs = nullptr; // diagnostic switches (null = defaults)
   uint32_t* err = nullptr;                  // device-visible error word: the persistent kernel ORs 1 into it when a counter wait expires
+  // Optional: the GroupNorm (+ SiLU) site that reads this conv's output, applied in the conv's epilogue where the kernel holds whole
+  // images x whole groups per wave (conv_small.inc.h): act_out = silu?(GN(out)) in out's layout; out itself only if act_raw; one touch
+  // of the next conv's packed weights (warm).  conv_launch reports through *act_done whether the launch did it (0: run the pass).
+  void* act_out = nullptr; const float* act_gamma = nullptr; const float* act_beta = nullptr;
+  const float* act_film = nullptr; int act_film_stride = 0; float act_eps = 1e-5f; int act_silu = 0, act_raw = 1;
+  const void* warm = nullptr; uint32_t warm_bytes = 0;
 };
 
 struct ConvGeom {
@@ -51,7 +57,7 @@ size_t conv_packed_weight_bytes(int dtype, int Cout, int Cin, int ks);
 int conv_tile_n(int Cout);
 // host-side packing: w_host [Cout][Cin][ks][ks] fp32 (Cin = logical input channels; padded to a chunk)
 void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks, void* dst_host);
-int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
+int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr, int* act_done = nullptr);
 // 1x1 GEMM with a stationary activation tile (conv1x1.hip): 0 = launched, 1 = not eligible, <0 = error
 int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
 

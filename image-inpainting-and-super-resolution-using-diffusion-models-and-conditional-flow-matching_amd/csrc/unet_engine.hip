@@ -524,6 +524,15 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   auto TP = [&](int id) -> void* { return id < 0 ? nullptr : ws + l.arena + net->tensors[id].offset_per_image * (size_t)B * esz; };
   auto SP = [&](int id) -> float* { return F(l.stats) + net->tensors[id].stats_off_per_image * (size_t)B; };
   std::vector<int> gn_slots(net->tensors.size(), 0);   // partial-statistics slots each tensor's producer filled in THIS forward
+  // GroupNorm sites the producing conv applied in its epilogue (small levels: ConvDesc::act_out); a tensor's raw copy is written only
+  // if an op other than that site reads it
+  std::vector<char> gn_done(net->ops.size(), 0);
+  std::vector<int> readers(net->tensors.size(), 0);
+  for (const PlanOp& o : net->ops) {
+    if (o.src0 >= 0) ++readers[o.src0];
+    if (o.src1 >= 0) ++readers[o.src1];
+    if (o.kind == OP_CONV && o.res >= 0) ++readers[o.res];
+  }
   int rc;
   auto mark = [&](const mi355_op_profile& r) {
     if (!run.prof) return;
@@ -552,7 +561,10 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     mi355_op_profile r{};
     const PlanTensor& s0 = net->tensors[op.src0];
     const int C1 = op.src1 >= 0 ? net->tensors[op.src1].C : 0;
-    if (op.kind == OP_GN && op.fin_ok && op.dst < 0 && gn_slots[op.src0] > 0 && (op.src1 < 0 || gn_slots[op.src1] > 0)) {
+    if (op.kind == OP_GN && gn_done[(size_t)(&op - net->ops.data())]) {
+      rc = 0;   // applied by the producing conv's epilogue
+      r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W; r.bytes = 0;
+    } else if (op.kind == OP_GN && op.fin_ok && op.dst < 0 && gn_slots[op.src0] > 0 && (op.src1 < 0 || gn_slots[op.src1] > 0)) {
       GnFinDesc g; g.stats0 = SP(op.src0); g.slots0 = gn_slots[op.src0]; g.C0 = s0.C;
       if (op.src1 >= 0) { g.stats1 = SP(op.src1); g.slots1 = gn_slots[op.src1]; g.C1 = C1; }
       g.N = B; g.HW = s0.H * s0.W; g.gamma = WF(op.gamma_off); g.beta = WF(op.beta_off);
@@ -591,9 +603,22 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       c.out_mode = op.out_mode;
       c.knobs = &net->knobs; c.err = net->err_dev;
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
-      int slots = 0;
+      int slots = 0, act_done = 0;
       if (op.dst >= 0 && net->tensors[op.dst].stats_cap) { c.gn_stats = SP(op.dst); c.gn_slots_cap = net->tensors[op.dst].stats_cap; }
-      rc = conv_launch(c, stream, &slots);
+      const size_t oi = (size_t)(&op - net->ops.data());
+      bool try_act = false;
+      if (op.dst >= 0 && op.out_mode == OUT_NHWC && oi + 1 < net->ops.size()) {
+        const PlanOp& g = net->ops[oi + 1];   // the apply-type GroupNorm site (small images) that reads this conv's output and nothing else
+        if (g.kind == OP_GN && g.dst >= 0 && g.src0 == op.dst && g.src1 < 0 && g.gn_site < 0) {
+          c.act_out = TP(g.dst); c.act_gamma = WF(g.gamma_off); c.act_beta = WF(g.beta_off);
+          if (g.film_emb_off >= 0) { c.act_film = embp + g.film_emb_off; c.act_film_stride = estride; }
+          c.act_silu = g.pro_silu; c.act_raw = readers[op.dst] > 1;
+          warm_next(g, c.warm, c.warm_bytes, 1);
+          try_act = true;
+        }
+      }
+      rc = conv_launch(c, stream, &slots, try_act ? &act_done : nullptr);
+      if (act_done) gn_done[oi + 1] = 1;
       if (op.dst >= 0) gn_slots[op.dst] = slots;
       if (run.prof) {
         const ConvGeom cg = conv_geometry(c);

@@ -56,7 +56,9 @@ typedef struct mi355_debug_config {
   int32_t gn_fuse;         /* 1: GroupNorm statistics come from partial sums in the producing convs' epilogues where possible */
   int32_t l2_warm;         /* 1: bit 0: statistics / apply passes touch the next conv's weights; bit 1: finalize passes too */
   int32_t attn_fused;      /* 1: GroupNorm-apply + qkv + attention in one kernel where the shape allows */
-  int32_t reserved[5];
+  int32_t gn_epilogue;     /* 1: at the 8x8 / 4x4 levels a GroupNorm (+SiLU) site whose only source is a small-level conv's output is applied in
+                            *    that conv's epilogue (no pass); 0: gn_affine pass */
+  int32_t reserved[4];
 } mi355_debug_config;
 void mi355_debug_defaults(mi355_debug_config* out);
 

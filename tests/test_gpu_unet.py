@@ -439,9 +439,54 @@ def test_engine_error_word_and_diagnostic_switches():
     base = e0.forward(x, t).cpu()
     torch.cuda.synchronize(); e0.check()
     variants = [dict(conv_ws=0), dict(conv_small=0), dict(conv_ws=0, conv_small=0, conv_min_wgs=100000), dict(gn_fuse=0), dict(attn_fused=0),
-                dict(gn_apply_max_hw=0), dict(gn_apply_max_hw=4096), dict(l2_warm=0), dict(l2_warm=3), dict(conv_stagger=1, conv_ws=0)]
+                dict(gn_apply_max_hw=0), dict(gn_apply_max_hw=4096), dict(l2_warm=0), dict(l2_warm=3), dict(conv_stagger=1, conv_ws=0),
+                dict(gn_epilogue=0)]
     for kn in variants:
         _, e = run(**kn)
         y = e.forward(x, t).cpu()
         torch.cuda.synchronize(); e.check()
         torch.testing.assert_close(y, base, rtol=2e-4, atol=5e-5, msg=lambda m, kn=kn: f"{kn}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("film", [False, True])
+def test_groupnorm_in_small_conv_epilogue_matches_pass(film):
+    """At the 8x8 / 4x4 levels the GroupNorm (+SiLU, +FiLM) site behind a small-level conv is applied in that conv's epilogue (a wave
+    holds whole images x whole groups: conv_small.inc.h) instead of a gn_affine pass (GroupNorm32, AD/image_diffusion/nn.py:11-13;
+    FiLM unet.py:343-347).  Same forward with the switch off: fp32 to rounding (the epilogue takes its statistics from the fp32
+    accumulators, the pass from the stored tensor - identical in fp32 mode up to summation order), bf16 within a fraction of the
+    mode's own error.  B = 256 runs the 8x8 kernel with one image per workgroup and the 4x4 kernel with K-sharing waves; B = 8 leaves
+    the 8x8 level on the pass (its waves share K: no wave-local statistics) and exercises the mixed plan."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import debug_config
+
+    kw = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+              channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64, use_scale_shift_norm=film)
+    sd = None
+
+    def run(precision, B, **knobs):
+        nonlocal sd
+        net = UNetModel(precision=precision, **kw)
+        if sd is None:
+            sd = synth_state_dict(param_shapes(net), 5201)
+        net.load_state_dict(sd)
+        net.debug = debug_config(**knobs)
+        net.to(DEV)
+        x = randn(5200, B, 3, 32, 32).to(DEV)
+        t = torch.linspace(0, 1, B).to(DEV)
+        e = net.engine(DEV)
+        y = e.forward(x, t).cpu()
+        torch.cuda.synchronize(); e.check()
+        return y
+
+    for B in (256, 8):
+        a = run("fp32", B, gn_epilogue=1)
+        b = run("fp32", B, gn_epilogue=0)
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=5e-5)
+    a = run("bf16", 256, gn_epilogue=1)
+    b = run("bf16", 256, gn_epilogue=0)
+    ref = run("fp32", 256, gn_epilogue=0)
+    scale = ref.abs().max().item()
+    ea, eb = (a - ref).pow(2).mean().sqrt().item(), (b - ref).pow(2).mean().sqrt().item()
+    assert ea < 0.02 * scale and ea < 1.5 * eb + 1e-3 * scale, (ea, eb, scale)   # not worse than the pass against the fp32 result
