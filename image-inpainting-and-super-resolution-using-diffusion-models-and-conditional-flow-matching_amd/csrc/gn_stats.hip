@@ -39,6 +39,13 @@ __global__ void __launch_bounds__(GN_THREADS + 64) gn_affine_kernel(GnKArgs p) {
   if (tid >= GN_THREADS) { l2_warm_wave(p.warm, p.warm_bytes); return; }   // the extra wave (launched only when there is something to warm)
   const int frag = tid % CV, prow = tid / CV;
   const int cb = frag * V;
+  // this thread's channel parameters travel with the activation reads (they do not depend on the statistics)
+  float pg, pbt, psc = 0.f, psh = 0.f;
+  {
+    const int c = min(tid, C - 1);
+    pg = p.gamma[c]; pbt = p.beta[c];
+    if (p.film) { psc = p.film[(size_t)n * p.film_stride + c]; psh = p.film[(size_t)n * p.film_stride + C + c]; }
+  }
   float s[V], q[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { s[j] = 0.f; q[j] = 0.f; }
@@ -92,11 +99,12 @@ __global__ void __launch_bounds__(GN_THREADS + 64) gn_affine_kernel(GnKArgs p) {
   __syncthreads();
   for (int c = tid; c < C; c += GN_THREADS) {
     const int g = c / cpg;
-    float a = g_rstd[g] * p.gamma[c];
-    float b = p.beta[c] - g_mean[g] * a;
+    const bool mine = c == tid;   // the first sweep uses the prefetched parameters
+    float a = g_rstd[g] * (mine ? pg : p.gamma[c]);
+    float b = (mine ? pbt : p.beta[c]) - g_mean[g] * a;
     if (p.film) {
-      const float sc = 1.0f + p.film[(size_t)n * p.film_stride + c];
-      const float sh = p.film[(size_t)n * p.film_stride + C + c];
+      const float sc = 1.0f + (mine ? psc : p.film[(size_t)n * p.film_stride + c]);
+      const float sh = mine ? psh : p.film[(size_t)n * p.film_stride + C + c];
       a *= sc;
       b = b * sc + sh;
     }
@@ -151,6 +159,15 @@ __global__ void __launch_bounds__(320) gn_finalize_kernel(GnFinArgs p) {
   float* g_rstd = g_mean + p.groups;
   const int tid = threadIdx.x, n = blockIdx.x;
   if (tid >= 256) { l2_warm_wave(p.warm, p.warm_bytes); return; }
+  // the per-channel parameters of this thread's (up to two) channels are requested FIRST: they do not depend on the statistics, and
+  // the kernel is nothing but dependent round trips (partials -> group statistics -> (a, b)), so they travel with the partials
+  float pg[2], pbt[2], psc[2] = {0.f, 0.f}, psh[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = min(tid + 256 * k, C - 1);
+    pg[k] = p.gamma[c]; pbt[k] = p.beta[c];
+    if (p.film) { psc[k] = p.film[(size_t)n * p.film_stride + c]; psh[k] = p.film[(size_t)n * p.film_stride + C + c]; }
+  }
   for (int q = tid; q < Q; q += 256) {
     const bool first = q < Q0;
     const float* base = first ? p.st0 + ((size_t)n * p.slots0 * Q0 + q) * 2 : p.st1 + ((size_t)n * p.slots1 * Q1 + (q - Q0)) * 2;
@@ -183,7 +200,23 @@ __global__ void __launch_bounds__(320) gn_finalize_kernel(GnFinArgs p) {
     g_rstd[tid] = 1.0f / sqrtf(var + p.eps);
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = tid + 256 * k;
+    if (c < C) {
+      const int g = c / cpg;
+      float a = g_rstd[g] * pg[k];
+      float b = pbt[k] - g_mean[g] * a;
+      if (p.film) {
+        const float sc = 1.0f + psc[k];
+        a *= sc;
+        b = b * sc + psh[k];
+      }
+      p.a[(size_t)n * C + c] = a;
+      p.b[(size_t)n * C + c] = b;
+    }
+  }
+  for (int c = tid + 512; c < C; c += 256) {   // more than 512 channels: the rest the slow way
     const int g = c / cpg;
     float a = g_rstd[g] * p.gamma[c];
     float b = p.beta[c] - g_mean[g] * a;
