@@ -1,0 +1,15 @@
+#!/bin/bash
+# GroupNorm (a, b) at the tail of the producing persistent conv (MI355_GN_FIN_TAIL): parity subset, then same-box interleaved A/B:
+# previous library / new library with the launch / new library with the tail
+D=$PWD/image-inpainting-and-super-resolution-using-diffusion-models-and-conditional-flow-matching_amd/csrc
+O=gpurun_out/r3_tail; mkdir -p $O
+if [ -z "$SKIPTESTS" ]; then
+timeout -k 10 700 python -m pytest tests/test_gpu_unet.py tests/test_gpu_configs.py -x -q -m gpu > $O/tests.txt 2>&1; tail -4 $O/tests.txt
+grep -q " passed" $O/tests.txt || exit 1
+grep -q "failed" $O/tests.txt && exit 1
+fi
+for i in 1 2 3; do
+  MI355_SAMPLER_LIB=$D/libmi355_sampler_old.so python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-110 | sed "s/^/prev    /"
+  MI355_GN_FIN_TAIL=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-110 | sed "s/^/launch  /"
+  python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-110 | sed "s/^/tail    /"
+done | tee $O/ab.txt
