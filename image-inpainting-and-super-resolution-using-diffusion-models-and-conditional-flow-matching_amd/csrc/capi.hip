@@ -134,7 +134,7 @@ int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, floa
 
 int mi355_unet_get_stats(const mi355_unet* net, int batch, mi355_unet_stats* out) {
   if (!net || !out) { mi355_set_error("null argument"); return -1; }
-  out->launches = net->launches;
+  out->launches = net->last_launches > 0 ? net->last_launches : net->launches;   // the most recent forward's real count once there was one
   out->conv_flops = net->conv_flops * batch;
   out->attn_flops = net->attn_flops * batch;
   out->act_bytes = net->act_bytes * batch;

@@ -65,7 +65,8 @@ struct mi355_unet {
   int in_tensor = -1, out_channels = 0;
   // stats per image
   double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;
-  int64_t launches = 0;   // device launches of one forward (fixed by the plan)
+  int64_t launches = 0;   // device launches of one forward as planned (an upper bound: a GroupNorm pass a conv epilogue absorbed is not launched)
+  mutable int64_t last_launches = 0;   // what the most recent forward really launched (0 before the first)
 };
 
 // Per-call options of unet_forward.  They are arguments, not handle state: a handle is immutable after unet_build, so one

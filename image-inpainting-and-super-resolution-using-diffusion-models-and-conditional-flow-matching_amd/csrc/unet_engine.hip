@@ -655,5 +655,10 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     if (rc) return rc;
     mark(r);
   }
+  {
+    int64_t skipped = 0;
+    for (char d : gn_done) skipped += d;
+    net->last_launches = net->launches - skipped - (run.emb_row ? 4 : 0);
+  }
   return 0;
 }

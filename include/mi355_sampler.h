@@ -138,7 +138,7 @@ int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, floa
 
 /* Launch/traffic counters of the last forward (host side bookkeeping, for bench.py's roofline). */
 typedef struct mi355_unet_stats {
-  int64_t launches;
+  int64_t launches; /* device launches of the most recent forward (the planned count before the first one) */
   double conv_flops;      /* 2*MAC of all conv/1x1/linear contractions        */
   double attn_flops;      /* 2*MAC of QK^T and PV                             */
   double act_bytes;       /* algorithmic activation bytes (in + out of each contraction op) */
