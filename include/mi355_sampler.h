@@ -131,7 +131,9 @@ int mi355_unet_vjp(mi355_unet* net, const float* grad_out, float* grad_x, int x_
 
 /* Diagnostics: the plan's ops (kind, src0, src1, dst, mode, ks, Cout, use_pro, pro_silu, res, res_mode, gn_site, heads, ch, dst C, dst H;
  * returns the op count) and an activation (or, differentiable plans, its gradient from the last mi355_unet_vjp) as NCHW fp32
- * [B, C, H, W] - the per-tensor view the reference gives through forward hooks / autograd on AD/image_diffusion/unet.py. */
+ * [B, C, H, W] - the per-tensor view the reference gives through forward hooks / autograd on AD/image_diffusion/unet.py.
+ * A non-differentiable plan does not materialise a conv output that nothing but a GroupNorm site fused into that conv's epilogue
+ * reads (8x8 / 4x4 levels; its activated copy is the site's dst tensor): create the handle with debug.gn_epilogue = 0 to inspect it. */
 int mi355_unet_plan_op(const mi355_unet* net, int index, int32_t fields[16]);
 int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, float* out, int batch, void* workspace, int64_t workspace_bytes,
                            void* stream);
