@@ -71,7 +71,12 @@ def test_state_dict_layout_matches_engine(golden):
 
 
 def test_batch_independence_and_large_batch():
-    """Per-sample independence (what makes batch sharding exact): image k of a 37-image batch == the same image alone."""
+    """Per-sample independence (what makes batch sharding exact): image k of a 37-image batch == the same image alone.
+    Tolerance: the two runs are the same arithmetic in a different ORDER, not bit-identical - the launch geometry depends on the batch
+    (a 1-image launch takes 64-pixel tiles and, at the small levels, K-sharing waves whose partial sums meet in LDS; the 37-image
+    launch takes 128-pixel tiles with K in one wave; the attention kernel defers its softmax rescale per wave), so fp32 sums of up to
+    2304 products associate differently: measured 1.1e-6 absolute at outputs of magnitude ~1 (a few fp32 ulps); 3e-6 leaves a margin
+    of 3x and is 60x below the 2e-4 the forward is held to against the oracle."""
     cfg = unet_ref.UNetConfig(16, 3, 32, 3, 1, (2,), channel_mult=(1, 2), num_heads=2)
     net, _ = build(cfg, 1003, "fp32")
     x = randn(99, 37, 3, 16, 16).to(DEV)
