@@ -31,6 +31,18 @@
 #ifndef WS_ABLATE
 #define WS_ABLATE 0   // diagnostic builds only: 4 = consumers skip LDS reads + MFMA, 8 = no weight loads, 16 = no patch loads, 64 = no weight LDS writes
 #endif
+// poll back-off of the counter waits, in units of 64 cycles: wait_ge (the loaders' buffer-free wait, the consumers' once-per-tile wait)
+// and release_acquire (the consumers' row hand-over).  The loaders run ahead and wait for a free buffer most of the time; every poll
+// costs the MFMA wave on the same SIMD issue slots, and a late wake-up costs nothing while the ring holds a row of slack: same box,
+// 1 / 2 / 8 / 16 / 32 -> 1250-1260 / +0.1 / +0.2-0.3 / +0.3 / +0.15 % end to end; 0 for the consumers' hand-over -0.1 %.
+#ifndef WS_LSLEEP
+#define WS_LSLEEP 8
+#endif
+#ifndef WS_CSLEEP
+#define WS_CSLEEP 1
+#endif
+#define WS_STR2(x) #x
+#define WS_STR(x) WS_STR2(x)
 namespace ws {
 constexpr int VW = 16, TH = 16, PW = VW + 2, PH = TH + 2, NPX = PW * PH;   // 18 x 18 = 324 patch pixels
 constexpr int PIT = 6, FR = 64, PLANE = NPX * 64;                           // 20,736 B per patch plane: dense 64-B pixel rows, the 16-B slots
@@ -156,7 +168,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         "s_sub_u32 %5, %5, 1\n\t"
         "s_cmp_eq_u32 %5, 0\n\t"
         "s_cbranch_scc1 4f\n\t"
-        "s_sleep 1\n\t"
+        "s_sleep " WS_STR(WS_LSLEEP) "\n\t"
         "s_branch 1b\n\t"
         "4:\n\t"                                  // gave up: flag the launch (one lane, no return value), then go on
         "s_cmp_eq_u64 %8, 0\n\t"
@@ -209,7 +221,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         "s_sub_u32 %5, %5, 1\n\t"
         "s_cmp_eq_u32 %5, 0\n\t"
         "s_cbranch_scc1 4f\n\t"
-        "s_sleep 1\n\t"
+        "s_sleep " WS_STR(WS_CSLEEP) "\n\t"
         "s_branch 1b\n\t"
         "4:\n\t"
         "s_cmp_eq_u64 %10, 0\n\t"
