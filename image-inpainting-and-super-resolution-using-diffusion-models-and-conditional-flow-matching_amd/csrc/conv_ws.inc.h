@@ -39,7 +39,7 @@
 #define WS_LSLEEP 8
 #endif
 #ifndef WS_CSLEEP
-#define WS_CSLEEP 1
+#define WS_CSLEEP 2   // consumers' hand-over (with WS_LSLEEP 8): 1 / 2 / 4 -> 1262.2 / 1265.3 / 1264.7 images/s
 #endif
 #define WS_STR2(x) #x
 #define WS_STR(x) WS_STR2(x)
