@@ -240,7 +240,6 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
       for (int u = 0; u < PIT; ++u) *reinterpret_cast<u32x4*>(dst + u * FR * PROW) = raw[pl][u];
       return;
     }
-    const int cb = c * CHUNK;
 #pragma unroll
     for (int u = 0; u < PIT; ++u) {
       float av[V], bv[V];

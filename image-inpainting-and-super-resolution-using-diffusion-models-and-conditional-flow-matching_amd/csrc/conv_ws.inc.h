@@ -98,7 +98,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   using namespace ws;
   using E = Elem<T>;
   constexpr int V = E::VEC, CHUNK = E::CHUNK, ESZ = sizeof(T);
-  constexpr bool FAST = (E::DTYPE == 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* pbuf = smem;                       // NPLANES patch planes
   char* wbuf = smem + NPLANES * PLANE;     // NWBUF x (3 weight tiles of one kernel row)
