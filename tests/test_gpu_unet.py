@@ -461,7 +461,7 @@ def test_groupnorm_in_small_conv_epilogue_matches_pass(film):
     FiLM unet.py:343-347).  Same forward with the switch off: fp32 to rounding (the epilogue takes its statistics from the fp32
     accumulators, the pass from the stored tensor - identical in fp32 mode up to summation order), bf16 within a fraction of the
     mode's own error.  B = 256 runs the 8x8 kernel with one image per workgroup and the 4x4 kernel with K-sharing waves; B = 8 leaves
-    the 8x8 level on the pass (its waves share K: no wave-local statistics) and exercises the mixed plan."""
+    the 8x8 level on the pass (its waves share K: no wave-local statistics) and exercises the mixed plan; B = 258 has a ragged last tile."""
     from image_diffusion.unet import UNetModel, param_shapes
     from mi355._lib import debug_config
 
@@ -484,7 +484,7 @@ def test_groupnorm_in_small_conv_epilogue_matches_pass(film):
         torch.cuda.synchronize(); e.check()
         return y
 
-    for B in (256, 8):
+    for B in (256, 258, 8):   # 258: the last 4x4 tile holds two real images and two slots beyond the batch
         a = run("fp32", B, gn_epilogue=1)
         b = run("fp32", B, gn_epilogue=0)
         assert torch.isfinite(a).all()
