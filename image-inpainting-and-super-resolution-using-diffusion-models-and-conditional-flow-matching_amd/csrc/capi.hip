@@ -464,8 +464,10 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   d.out = nhwc ? yout : (void*)y;
 #ifdef CONV_STAMPS
   const size_t nwaves = (size_t)g.grid_m * g.grid_n * 4;
-  MI355_REQUIRE(p + nwaves * 64 <= end, -2, "conv2d: workspace too small (stamps)");
-  MI355_CHECK_HIP(hipMemsetAsync(p, 0, nwaves * 64, s));
+  MI355_REQUIRE(p + 65536 + nwaves * 64 <= end, -2, "conv2d: workspace too small (stamps)");
+  MI355_CHECK_HIP(hipMemsetAsync(p, 0, 65536 + nwaves * 64, s));
+  unsigned long long* clk = reinterpret_cast<unsigned long long*>(p);   // [4096 waves][shader cycles, 100-MHz ticks]: CLK_FLUSH
+  p += 65536;
   d.dbg = p;
 #endif
   if ((rc = conv_launch(d, s))) return rc;
@@ -502,6 +504,16 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
     double h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
     for (size_t w = 0; w < nwaves; ++w) for (int k = 0; k < 8; ++k) h[k] += (double)hv[w * 8 + k];
     for (int k = 0; k < 8; ++k) tot += h[k];
+    {   // in-kernel clock of the LAST launch (after conv_time_reps back-to-back launches: the sustained clock), median over waves
+      std::vector<unsigned long long> hc(8192);
+      MI355_CHECK_HIP(hipMemcpy(hc.data(), clk, 65536, hipMemcpyDeviceToHost));
+      std::vector<double> mhz;
+      for (size_t w = 0; w < 4096; ++w) if (hc[2 * w + 1] > 0) mhz.push_back(100.0 * (double)hc[2 * w] / (double)hc[2 * w + 1]);
+      if (!mhz.empty()) {
+        std::sort(mhz.begin(), mhz.end());
+        fprintf(stderr, "[conv clock] %zu waves: in-kernel clock min %.0f median %.0f max %.0f MHz\n", mhz.size(), mhz.front(), mhz[mhz.size() / 2], mhz.back());
+      }
+    }
     if (tot > 0) {
       fprintf(stderr, "[conv stamps] waves %zu, cycles/wave %.0f:", nwaves, tot / nwaves);
       for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f (%.1f%%)", names[k], h[k] / nwaves, 100.0 * h[k] / tot);

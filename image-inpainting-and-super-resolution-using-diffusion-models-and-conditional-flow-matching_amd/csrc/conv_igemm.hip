@@ -67,10 +67,16 @@ __device__ __forceinline__ unsigned long long conv_stamp() {
 #define STAMP_DECL unsigned long long st_prev = conv_stamp(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(k) { const unsigned long long st_now = conv_stamp(); st_acc[k] += st_now - st_prev; st_prev = st_now; }
 #define STAMP_FLUSH if (p.dbg && (threadIdx.x & 63) == 0) { unsigned long long* q = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6)) * 8; for (int k = 0; k < 8; ++k) q[k] = st_acc[k]; }
+// In-kernel clock of a wave (MI355X_MICROARCH.md, DVFS give-back item 6): shader-clock cycles per 100-MHz reference tick over the wave's
+// life time; two u64 per wave in the 64 KB in FRONT of the stamp buffer (the persistent conv's consumer waves only).
+#define CLK_DECL const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#define CLK_FLUSH if (p.dbg && (threadIdx.x & 63) == 0) { unsigned long long* q = p.dbg - 8192 + ((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 2; q[0] = __builtin_amdgcn_s_memtime() - ck_t0; q[1] = __builtin_amdgcn_s_memrealtime() - ck_r0; }
 #else
 #define STAMP_DECL
 #define STAMP(k)
 #define STAMP_FLUSH
+#define CLK_DECL
+#define CLK_FLUSH
 #endif
 
 template <int I> struct IC { static constexpr int value = I; };

@@ -658,6 +658,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       cpar ^= 1;
     };
     STAMP_DECL
+    CLK_DECL
     // row state of the stream of kernel rows (continuous across chunks and tiles)
     int ky = 0, plane = 0, sel = 0;   // the fragment addresses move by wave-uniform steps (no per-lane base registers kept)
     uint32_t rowc = 0;
@@ -873,6 +874,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       t = t_next;
     }
     STAMP_FLUSH
+    CLK_FLUSH
   }
 }
 
