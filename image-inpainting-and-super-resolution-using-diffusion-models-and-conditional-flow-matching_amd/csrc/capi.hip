@@ -35,7 +35,7 @@ void mi355_debug_defaults(mi355_debug_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
   c->conv_ws = 1; c->conv_small = 1; c->conv_min_wgs = 512; c->conv_stagger = 0; c->conv_ablate = 0; c->conv_spin_limit = 1 << 22;
-  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 1;
+  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 1; c->conv_pp = 1;
 }
 int mi355_unet_status(mi355_unet* net, int clear) {
   if (!net) { mi355_set_error("null handle"); return -1; }
@@ -514,7 +514,35 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
         fprintf(stderr, "[conv clock] %zu waves: in-kernel clock min %.0f median %.0f max %.0f MHz\n", mhz.size(), mhz.front(), mhz[mhz.size() / 2], mhz.back());
       }
     }
-    if (tot > 0) {
+    if (g.BM == 256 && g.BN == 256 && nwaves * 8 >= 2048 * 8 + 160) {   // timeline of workgroup 0, taps 8 .. 11 (PP_TRACE): cycles relative to wave 0's first stamp
+      const unsigned long long* tr = hv.data() + 2048 * 8;
+      const unsigned long long t0 = tr[0];
+      static const char* ev[5] = {"issued", "vmcnt", "barL", "mfma", "barM"};
+      for (int w = 0; w < 8; ++w) {
+        fprintf(stderr, "[pp trace] wave %d:", w);
+        for (int i = 0; i < 20; ++i) fprintf(stderr, " %s%d=%lld", ev[i % 5], 8 + i / 5, (long long)(tr[w * 20 + i] - t0));
+        fprintf(stderr, "\n");
+      }
+    }
+    if (g.BM == 256 && g.BN == 256) {   // ping-pong kernel (conv_pp.inc.h): 8 waves per workgroup, waves 0-3 = group 0, 4-7 = group 1 (one tick behind)
+      static const char* names_pp[8] = {"L:reads+dma", "L:vmcnt", "L:barrier", "M:mfma", "M:barrier", "E:epilogue", "E:rejoin", "tile_head"};
+      for (int grp = 0; grp < 2; ++grp) {
+        double hp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0; size_t nw = 0;
+        for (size_t w = 0; w < nwaves; ++w) {
+          if (((w >> 2) & 1) != (size_t)grp) continue;
+          double tw = 0;
+          for (int k = 0; k < 8; ++k) tw += (double)hv[w * 8 + k];
+          if (tw == 0) continue;
+          ++nw;
+          for (int k = 0; k < 8; ++k) hp[k] += (double)hv[w * 8 + k];
+          tp += tw;
+        }
+        if (!nw) continue;
+        fprintf(stderr, "[conv stamps] ping-pong group %d, waves %zu, cycles/wave %.0f:", grp, nw, tp / nw);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f (%.1f%%)", names_pp[k], hp[k] / nw, 100.0 * hp[k] / tp);
+        fprintf(stderr, "\n");
+      }
+    } else if (tot > 0) {
       fprintf(stderr, "[conv stamps] waves %zu, cycles/wave %.0f:", nwaves, tot / nwaves);
       for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f (%.1f%%)", names[k], h[k] / nwaves, 100.0 * h[k] / tot);
       fprintf(stderr, "\n");

@@ -581,6 +581,7 @@ int launch_cfg(const ConvKArgs& a, int BM, int BN, int ks, int pit, dim3 grid, s
 }
 
 #include "conv_ws.inc.h"
+#include "conv_pp.inc.h"
 #include "conv_small.inc.h"
 
 struct Geo {
@@ -706,6 +707,12 @@ ConvGeom conv_geometry(const ConvDesc& d) {
   r.Ho = g.Ho; r.Wo = g.Wo; r.BM = g.BM; r.BN = g.BN; r.lds_bytes = g.lds;
   r.grid_m = g.groups * g.tiles_x * g.tiles_y; r.grid_n = (d.Cout + g.BN - 1) / g.BN;
   const int CH = d.dtype == 0 ? 16 : 32;
+  const mi355_debug_config& Kg = d.knobs ? *d.knobs : mi355_default_debug();
+  if (d.C0 % CH == 0 && d.C1 % CH == 0 &&
+      pp_eligible(Kg.conv_pp, d.ks, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.pro_a != nullptr, d.N, g.Ho, g.Wo, d.Cout)) {
+    r.BM = 256; r.BN = 256; r.lds_bytes = pp::LDS_BYTES;   // ping-pong kernel (conv_pp.inc.h)
+    return r;
+  }
   if (d.C0 % CH == 0 && d.C1 % CH == 0 &&
       ws_eligible((d.knobs ? d.knobs : &mi355_default_debug())->conv_ws, d.ks, g.BM, g.BN, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.N, g.Ho, g.Wo, d.Cout)) {
     r.BM = 256; r.lds_bytes = ws::LDS_BYTES;   // warp-specialised persistent kernel: 16 x 16 pixel tiles (grid_m / grid_n stay the plain launch's: workspace sizing)
@@ -759,6 +766,14 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
   dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
   const bool gn_ok = d.gn_stats && d.out_mode == OUT_NHWC && g.G == 1 && d.Cout % g.BN == 0 && d.Cout % 4 == 0;
+  {   // prologue-free inputs, 256-channel output tiles: ping-pong kernel (conv_pp.inc.h); same statistics slots as the warp-specialised kernel
+    const int pp_slots = 2 * ((g.Wo + pp::VW - 1) / pp::VW) * ((g.Ho + pp::TH - 1) / pp::TH);
+    if (gn_ok && pp_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = pp_slots; }
+    const int r = d.dtype == 0 ? launch_pp<float>(a, K.conv_pp, d.ks, stream) : launch_pp<bf16>(a, K.conv_pp, d.ks, stream);
+    if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); if (gn_slots_used) *gn_slots_used = a.gn_slots; return 0; }
+    if (r < 0) return r;
+    a.gn_stats = nullptr; a.gn_slots = 0;
+  }
   {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
     const int ws_slots = 2 * ((g.Wo + ws::VW - 1) / ws::VW) * ((g.Ho + ws::TH - 1) / ws::TH);   // (16x16 pixel tile, 8-row half) per image
     if (gn_ok && ws_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = ws_slots; }

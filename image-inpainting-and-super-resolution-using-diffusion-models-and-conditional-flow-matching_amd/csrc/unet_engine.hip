@@ -516,7 +516,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   const WsLayout l = ws_layout(net, B);
   MI355_REQUIRE((int64_t)l.total <= workspace_bytes, -2, "unet_forward: workspace too small");
   MI355_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, -1, "unet_forward: workspace must be 256-byte aligned");
-  const int dtype = net->cfg.dtype, esz = dtype == 0 ? 4 : 2, mc = net->cfg.model_channels;
+  const int dtype = net->cfg.dtype, esz = dtype == 0 ? 4 : 2;
   char* ws = reinterpret_cast<char*>(workspace);
   char* W = net->dev_weights;
   auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };

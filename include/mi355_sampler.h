@@ -58,7 +58,10 @@ typedef struct mi355_debug_config {
   int32_t attn_fused;      /* 1: GroupNorm-apply + qkv + attention in one kernel where the shape allows */
   int32_t gn_epilogue;     /* 1: at the 8x8 / 4x4 levels a GroupNorm (+SiLU) site whose only source is a small-level conv's output is applied in
                             *    that conv's epilogue (no pass); 0: gn_affine pass */
-  int32_t reserved[4];
+  int32_t conv_pp;         /* 1: prologue-free 3x3 convs with Cout % 256 == 0 on images >= 16x16 run on the ping-pong kernel (conv_pp.inc.h: 8 MFMA
+                            *    waves in two groups that alternate LDS-read / DMA segments with MFMA segments) when the launch has at least one
+                            *    256-pixel x 256-channel tile per CU; 2: whenever the shape is eligible (tests); 0: never */
+  int32_t reserved[3];
 } mi355_debug_config;
 void mi355_debug_defaults(mi355_debug_config* out);
 

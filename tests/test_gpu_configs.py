@@ -150,6 +150,62 @@ def test_ws_conv_concat_residual_emb(case, dtype, rtol, atol):
     torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
 
 
+PP_CASES = [
+    # B, C0, C1, H, Cout, resample, emb, res_mode       prologue-free 3x3 convs with Cout % 256 == 0 => conv3x3_pp_kernel (conv_pp.inc.h), forced
+    (6, 256, 0, 16, 256, 0, True, 1),        # ResBlock out_layers at 16x16 fed by an activated tensor: one tile per image, emb + residual
+    (300, 256, 0, 16, 256, 0, False, 0),     # more tiles than CUs: the persistent walk, the DMA stream crossing tile boundaries, uneven walks
+    (40, 256, 256, 16, 256, 0, True, 0),     # two sources (the patch stream switches descriptors half way), 16 chunks
+    (33, 128, 0, 16, 256, 2, True, 0),       # Upsample.conv 16 -> 32: nearest x2 gather in the pieces' source addresses, four tiles per image
+    (10, 128, 64, 28, 256, 0, False, 2),     # ragged 28x28 image: partial tiles in x and y, 6 chunks, RES_UP2 residual
+    (5, 64, 0, 32, 512, 0, True, 1),         # two 256-channel tiles per pixel tile (XCD-paired walk), the minimum of two chunks
+    (3, 128, 0, 20, 256, 0, False, 0),       # 2 x 2 tiles of a 20 x 20 image, tiny batch: fewer tiles than CUs
+]
+
+
+@pytest.mark.parametrize("case", PP_CASES)
+@pytest.mark.parametrize("dtype,rtol,atol", [(_lib.MI355_F32, 5e-5, 5e-5), (_lib.MI355_BF16, 3e-2, 3e-2)])
+def test_pingpong_conv(case, dtype, rtol, atol):
+    """conv3x3_pp_kernel vs F.conv2d(cat(...)) + emb + res (unet.py:307-311,351 out_layers; :209-212 Upsample.conv); conv_pp = 2 forces the
+    kernel for every eligible shape, conv_ablate = 64 replaces its counted epilogue window by a drain: both must give the same tensor."""
+    from mi355.ops import default_ops as ops
+
+    B, C0, C1, H, Co, resample, use_emb, res_mode = case
+    seed = 9000 + hash(case) % 1000
+    x = randn(seed, B, C0, H, H) * 1.3 + 0.1
+    x1 = randn(seed + 1, B, C1, H, H) * 0.7 - 0.2 if C1 else None
+    C = C0 + C1
+    sd = synth_state_dict({"weight": (Co, C, 3, 3), "bias": (Co,)}, seed + 2)
+    Ho = 2 * H if resample == 2 else H
+    emb = randn(seed + 3, B, Co) * 0.5 if use_emb else None
+    res = None
+    if res_mode == 1:
+        res = randn(seed + 4, B, Co, Ho, Ho)
+    elif res_mode == 2:
+        res = randn(seed + 4, B, Co, Ho // 2, Ho // 2)
+    h = x if x1 is None else torch.cat((x, x1), dim=1)
+    if resample == 2:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, sd["weight"], sd["bias"], padding=1)
+    if emb is not None:
+        ref = ref + emb[:, :, None, None]
+    if res_mode == 1:
+        ref = ref + res
+    elif res_mode == 2:
+        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+    outs = []
+    for abl in (0, 64):
+        outs.append(ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], resample=resample, dtype=dtype, x1=x1.to(DEV) if x1 is not None else None,
+                               emb=emb.to(DEV) if emb is not None else None, res=res.to(DEV) if res is not None else None,
+                               res_mode=res_mode or 1, debug=_lib.debug_config(conv_pp=2, conv_ablate=abl)).cpu())
+    torch.testing.assert_close(outs[0], ref, rtol=rtol, atol=atol)
+    assert torch.equal(outs[0], outs[1])
+    # the same launch on the kernels it replaces: bitwise equal in fp32 mode is not required (different summation trees), closeness is
+    old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], resample=resample, dtype=dtype, x1=x1.to(DEV) if x1 is not None else None,
+                     emb=emb.to(DEV) if emb is not None else None, res=res.to(DEV) if res is not None else None,
+                     res_mode=res_mode or 1, debug=_lib.debug_config(conv_pp=0)).cpu()
+    torch.testing.assert_close(outs[0], old, rtol=rtol, atol=atol)
+
+
 def test_small_tile_conv_concat_residual_emb_fp32():
     """The same epilogue / two-source paths on the plain (non-persistent) kernels: small batches, 8x8 multi-image tiles, 1x1."""
     from mi355.ops import default_ops as ops
