@@ -520,7 +520,7 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
       static const char* ev[5] = {"issued", "vmcnt", "barL", "mfma", "barM"};
       for (int w = 0; w < 8; ++w) {
         fprintf(stderr, "[pp trace] wave %d:", w);
-        for (int i = 0; i < 20; ++i) fprintf(stderr, " %s%d=%lld", ev[i % 5], 8 + i / 5, (long long)(tr[w * 20 + i] - t0));
+        for (int i = 0; i < 20; ++i) fprintf(stderr, " %s%d=%lld", ev[i % 5], 8 + i / 5, (long long)(int32_t)(uint32_t)(tr[w * 20 + i] - t0));
         fprintf(stderr, "\n");
       }
     }

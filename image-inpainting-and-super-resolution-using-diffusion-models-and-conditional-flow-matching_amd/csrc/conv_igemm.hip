@@ -581,7 +581,10 @@ int launch_cfg(const ConvKArgs& a, int BM, int BN, int ks, int pit, dim3 grid, s
 }
 
 #include "conv_ws.inc.h"
-#include "conv_pp.inc.h"
+#ifndef PP_IMPL   // experiments: make variant VARFLAGS='-DPP_IMPL="\"../../tools/experiments/<file>\""' VARTAG=_x builds a library around another version of the kernel
+#define PP_IMPL "conv_pp.inc.h"
+#endif
+#include PP_IMPL
 #include "conv_small.inc.h"
 
 struct Geo {
