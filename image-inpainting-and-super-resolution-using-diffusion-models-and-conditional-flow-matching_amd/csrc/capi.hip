@@ -35,7 +35,7 @@ void mi355_debug_defaults(mi355_debug_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
   c->conv_ws = 1; c->conv_small = 1; c->conv_min_wgs = 512; c->conv_stagger = 0; c->conv_ablate = 0; c->conv_spin_limit = 1 << 22;
-  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 1; c->conv_pp = 1;
+  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 3; c->conv_pp = 1;
 }
 int mi355_unet_status(mi355_unet* net, int clear) {
   if (!net) { mi355_set_error("null handle"); return -1; }
@@ -127,6 +127,14 @@ int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, floa
   const WsLayout l = unet_ws_layout(net, batch);
   MI355_REQUIRE((int64_t)l.total <= workspace_bytes, -2, "read_tensor: workspace too small");
   const PlanTensor& t = net->tensors[tensor];
+  if (!gradient && (size_t)tensor < net->tensor_state.size() && net->tensor_state[tensor]) {
+    mi355_set_error(net->tensor_state[tensor] == 1
+                        ? "read_tensor: the last forward did not materialise this conv output (its only reader, a GroupNorm site, ran in the conv's epilogue): "
+                          "create the handle with debug.gn_epilogue = 0 to inspect it"
+                        : "read_tensor: the last forward normalised this conv output in place (16x16 level: it holds silu(GroupNorm(.)), not the conv's result): "
+                          "create the handle with debug.gn_epilogue = 0 (or 1) to inspect it");
+    return MI355_ERR_UNSUPPORTED;
+  }
   const int esz = net->cfg.dtype == 0 ? 4 : 2;
   const char* p = reinterpret_cast<const char*>(workspace) + (gradient ? l.grads : l.arena) + t.offset_per_image * (size_t)batch * esz;
   return unpack_nchw_launch(net->cfg.dtype, p, batch, t.H * t.W, t.C, out, S(stream));

@@ -67,6 +67,10 @@ struct mi355_unet {
   double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;
   int64_t launches = 0;   // device launches of one forward as planned (an upper bound: a GroupNorm pass a conv epilogue absorbed is not launched)
   mutable int64_t last_launches = 0;   // what the most recent forward really launched (0 before the first)
+  // what the most recent forward left in each activation tensor (diagnostics: mi355_unet_read_tensor): 0 = the tensor as the reference
+  // defines it, 1 = never written (its only reader, a GroupNorm site, was fused into the producing conv's epilogue), 2 = overwritten in
+  // place by silu?(GroupNorm(.)) (16x16 level).  Sized at build; single bytes, so concurrent forwards of one handle only blur the record.
+  mutable std::vector<char> tensor_state;
 };
 
 // Per-call options of unet_forward.  They are arguments, not handle state: a handle is immutable after unet_build, so one

@@ -447,6 +447,7 @@ int unet_build(const mi355_unet_config& cfg, const float* const* params_host, in
   }
   if (rc) { delete net; return rc; }
   net->params = w.params;
+  net->tensor_state.assign(net->tensors.size(), 0);
   net->dev_weights = reinterpret_cast<char*>(dev_weights);
   net->dev_weights_bytes = (int64_t)w.cursor;
   *out = net;
@@ -527,6 +528,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   // GroupNorm sites the producing conv applied in its epilogue (small levels: ConvDesc::act_out); a tensor's raw copy is written only
   // if an op other than that site reads it
   std::vector<char> gn_done(net->ops.size(), 0);
+  std::vector<char> pro_off(net->ops.size(), 0);   // convs whose input arrives already normalised (16x16 level: applied IN PLACE by the producer)
   std::vector<int> readers(net->tensors.size(), 0);
   for (const PlanOp& o : net->ops) {
     if (o.src0 >= 0) ++readers[o.src0];
@@ -592,8 +594,9 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     } else if (op.kind == OP_CONV) {
       ConvDesc c; c.dtype = dtype; c.src0 = TP(op.src0); c.C0 = s0.C; c.src1 = TP(op.src1); c.C1 = C1;
       c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks;
-      if (op.use_pro) { c.pro_a = F(l.gna); c.pro_b = F(l.gnb); c.pro_silu = op.pro_silu; }
-      if (op.use_pro && op.gn_site >= 0) {
+      const size_t oi = (size_t)(&op - net->ops.data());
+      if (op.use_pro && !pro_off[oi]) { c.pro_a = F(l.gna); c.pro_b = F(l.gnb); c.pro_silu = op.pro_silu; }
+      if (op.use_pro && !pro_off[oi] && op.gn_site >= 0) {
         float* sp = F(l.sites) + net->site_off[op.gn_site] * (size_t)B;
         c.pro_a = sp; c.pro_b = sp + (size_t)B * net->site_C[op.gn_site];
       }
@@ -605,9 +608,26 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
       int slots = 0, act_done = 0;
       if (op.dst >= 0 && net->tensors[op.dst].stats_cap) { c.gn_stats = SP(op.dst); c.gn_slots_cap = net->tensors[op.dst].stats_cap; }
-      const size_t oi = (size_t)(&op - net->ops.data());
       bool try_act = false;
-      if (op.dst >= 0 && op.out_mode == OUT_NHWC && oi + 1 < net->ops.size()) {
+      size_t act_consumer = 0;
+      if (op.dst >= 0 && op.out_mode == OUT_NHWC && op.res < 0 && oi + 2 < net->ops.size() && readers[op.dst] == 2) {
+        // statistics-type site (larger images) read by exactly one prologue conv: where the persistent kernel's tile is the whole
+        // image (16x16) it normalises its own output in place, the site's launch disappears and the consumer runs prologue-free
+        const PlanOp& g = net->ops[oi + 1];
+        if (g.kind == OP_GN && g.fin_ok && g.dst < 0 && g.src0 == op.dst && g.src1 < 0 && g.gn_site < 0) {
+          for (size_t j = oi + 2; j < net->ops.size() && j <= oi + 3; ++j) {
+            const PlanOp& cn = net->ops[j];
+            if (cn.kind == OP_CONV && cn.use_pro && cn.src0 == op.dst && cn.src1 < 0 && cn.gn_site < 0) { act_consumer = j; break; }
+          }
+          if (act_consumer) {
+            c.act_out = c.out; c.act_raw = 0; c.act_gamma = WF(g.gamma_off); c.act_beta = WF(g.beta_off);
+            if (g.film_emb_off >= 0) { c.act_film = embp + g.film_emb_off; c.act_film_stride = estride; }
+            c.act_silu = net->ops[act_consumer].pro_silu;
+            try_act = true;
+          }
+        }
+      }
+      if (!try_act && op.dst >= 0 && op.out_mode == OUT_NHWC && oi + 1 < net->ops.size()) {
         const PlanOp& g = net->ops[oi + 1];   // the apply-type GroupNorm site (small images) that reads this conv's output and nothing else
         if (g.kind == OP_GN && g.dst >= 0 && g.src0 == op.dst && g.src1 < 0 && g.gn_site < 0) {
           c.act_out = TP(g.dst); c.act_gamma = WF(g.gamma_off); c.act_beta = WF(g.beta_off);
@@ -618,7 +638,8 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
         }
       }
       rc = conv_launch(c, stream, &slots, try_act ? &act_done : nullptr);
-      if (act_done) gn_done[oi + 1] = 1;
+      if (act_done) { gn_done[oi + 1] = 1; if (act_consumer) pro_off[act_consumer] = 1; }
+      if (op.dst >= 0 && (size_t)op.dst < net->tensor_state.size()) net->tensor_state[op.dst] = !act_done ? 0 : (act_consumer ? 2 : (c.act_raw ? 0 : 1));
       if (op.dst >= 0) gn_slots[op.dst] = slots;
       if (run.prof) {
         const ConvGeom cg = conv_geometry(c);

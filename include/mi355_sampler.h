@@ -56,8 +56,10 @@ typedef struct mi355_debug_config {
   int32_t gn_fuse;         /* 1: GroupNorm statistics come from partial sums in the producing convs' epilogues where possible */
   int32_t l2_warm;         /* 1: bit 0: statistics / apply passes touch the next conv's weights; bit 1: finalize passes too */
   int32_t attn_fused;      /* 1: GroupNorm-apply + qkv + attention in one kernel where the shape allows */
-  int32_t gn_epilogue;     /* 1: at the 8x8 / 4x4 levels a GroupNorm (+SiLU) site whose only source is a small-level conv's output is applied in
-                            *    that conv's epilogue (no pass); 0: gn_affine pass */
+  int32_t gn_epilogue;     /* 3: bit 0: at the 8x8 / 4x4 levels a GroupNorm (+SiLU) site whose only source is a small-level conv's output is applied in
+                            *    that conv's epilogue (no pass); bit 1: at the 16x16 level (a persistent-conv tile = a whole image) the first conv of
+                            *    a ResBlock normalises its own output in place (its own template instantiation), the site's finalize launch
+                            *    disappears and the second conv runs prologue-free; 0: gn_affine pass / finalize launch + prologue */
   int32_t conv_pp;         /* 1: prologue-free 3x3 convs with Cout % 256 == 0 on images >= 16x16 run on the ping-pong kernel (conv_pp.inc.h: 8 MFMA
                             *    waves in two groups that alternate LDS-read / DMA segments with MFMA segments) when the launch has at least one
                             *    256-pixel x 256-channel tile per CU; 2: whenever the shape is eligible (tests); 0: never */
@@ -136,7 +138,9 @@ int mi355_unet_vjp(mi355_unet* net, const float* grad_out, float* grad_x, int x_
  * returns the op count) and an activation (or, differentiable plans, its gradient from the last mi355_unet_vjp) as NCHW fp32
  * [B, C, H, W] - the per-tensor view the reference gives through forward hooks / autograd on AD/image_diffusion/unet.py.
  * A non-differentiable plan does not materialise a conv output that nothing but a GroupNorm site fused into that conv's epilogue
- * reads (8x8 / 4x4 levels; its activated copy is the site's dst tensor): create the handle with debug.gn_epilogue = 0 to inspect it. */
+ * reads (8x8 / 4x4 levels; its activated copy is the site's dst tensor), and at the 16x16 level the first conv of a ResBlock overwrites its
+ * output with silu(GroupNorm(.)) in place: for such a tensor mi355_unet_read_tensor returns MI355_ERR_UNSUPPORTED after the forward that
+ * did so (the record is per handle, of its most recent forward); create the handle with debug.gn_epilogue = 0 to inspect them. */
 int mi355_unet_plan_op(const mi355_unet* net, int index, int32_t fields[16]);
 int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, float* out, int batch, void* workspace, int64_t workspace_bytes,
                            void* stream);

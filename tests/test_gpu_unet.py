@@ -445,7 +445,7 @@ def test_engine_error_word_and_diagnostic_switches():
     torch.cuda.synchronize(); e0.check()
     variants = [dict(conv_ws=0), dict(conv_small=0), dict(conv_ws=0, conv_small=0, conv_min_wgs=100000), dict(gn_fuse=0), dict(attn_fused=0),
                 dict(gn_apply_max_hw=0), dict(gn_apply_max_hw=4096), dict(l2_warm=0), dict(l2_warm=3), dict(conv_stagger=1, conv_ws=0),
-                dict(gn_epilogue=0)]
+                dict(gn_epilogue=0), dict(gn_epilogue=1), dict(gn_epilogue=2), dict(conv_pp=0), dict(conv_pp=0, gn_epilogue=2), dict(conv_pp=2)]
     for kn in variants:
         _, e = run(**kn)
         y = e.forward(x, t).cpu()
@@ -485,7 +485,7 @@ def test_groupnorm_in_small_conv_epilogue_matches_pass(film):
         return y
 
     for B in (256, 258, 8):   # 258: the last 4x4 tile holds two real images and two slots beyond the batch
-        a = run("fp32", B, gn_epilogue=1)
+        a = run("fp32", B, gn_epilogue=1)   # bit 0 = the small-level epilogue alone
         b = run("fp32", B, gn_epilogue=0)
         assert torch.isfinite(a).all()
         torch.testing.assert_close(a, b, rtol=2e-4, atol=5e-5)
@@ -495,3 +495,57 @@ def test_groupnorm_in_small_conv_epilogue_matches_pass(film):
     scale = ref.abs().max().item()
     ea, eb = (a - ref).pow(2).mean().sqrt().item(), (b - ref).pow(2).mean().sqrt().item()
     assert ea < 0.02 * scale and ea < 1.5 * eb + 1e-3 * scale, (ea, eb, scale)   # not worse than the pass against the fp32 result
+
+
+@pytest.mark.gpu
+def test_groupnorm_in_place_at_16x16_matches_launch_and_read_tensor_reports_it():
+    """At the 16x16 level a persistent-conv tile is a whole image, so the first conv of a ResBlock (unet.py:283-286) applies the out_layers
+    GroupNorm + SiLU (unet.py:306-311; GroupNorm32 nn.py:11-13) to its own accumulators and stores the result IN PLACE (its own template
+    instantiation of conv3x3_ws_kernel); the site's finalize launch disappears and the second conv runs prologue-free on the ping-pong
+    kernel.  Same forward with bit 1 of gn_epilogue off: fp32 to rounding, bf16 not worse against the fp32 result.  The overwritten
+    tensors are no longer the reference's activations: mi355_unet_read_tensor must refuse them instead of returning garbage with rc 0."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import MI355BackendError, debug_config
+
+    kw = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+              channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
+    sd = None
+
+    def run(precision, B, **knobs):
+        nonlocal sd
+        net = UNetModel(precision=precision, **kw)
+        if sd is None:
+            sd = synth_state_dict(param_shapes(net), 5301)
+        net.load_state_dict(sd)
+        net.debug = debug_config(**knobs)
+        net.to(DEV)
+        x = randn(5300, B, 3, 32, 32).to(DEV)
+        t = torch.linspace(0, 1, B).to(DEV)
+        e = net.engine(DEV)
+        y = e.forward(x, t).cpu()
+        torch.cuda.synchronize(); e.check()
+        return y, e
+
+    for B in (256, 300):   # 300: more tiles than CUs (a second, shorter walk)
+        a, ea = run("fp32", B, gn_epilogue=3)
+        b, eb = run("fp32", B, gn_epilogue=1)
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=5e-5)
+        launches = (ea.stats(B)["launches"], eb.stats(B)["launches"])
+        assert launches[0] == launches[1] - 5, launches      # the five out_layers sites of the 16x16 ResBlocks
+        refused = {0: 0, 1: 0}
+        for which, e in enumerate((ea, eb)):
+            for op in e.plan_ops():
+                if op["kind"] != 1 or op["dst"] < 0:
+                    continue
+                try:
+                    e.read_tensor(op["dst"], B, (op["dst_c"], op["dst_h"], op["dst_h"]))
+                except MI355BackendError as err:
+                    refused[which] += "in place" in str(err)
+        assert refused == {0: 5, 1: 0}, refused
+    a, _ = run("bf16", 256, gn_epilogue=3)
+    b, _ = run("bf16", 256, gn_epilogue=1)
+    ref, _ = run("fp32", 256, gn_epilogue=0)
+    scale = ref.abs().max().item()
+    ea, eb = (a - ref).pow(2).mean().sqrt().item(), (b - ref).pow(2).mean().sqrt().item()
+    assert ea < 0.02 * scale and ea < 1.5 * eb + 1e-3 * scale, (ea, eb, scale)
