@@ -585,6 +585,7 @@ int launch_cfg(const ConvKArgs& a, int BM, int BN, int ks, int pit, dim3 grid, s
 #define PP_IMPL "conv_pp.inc.h"
 #endif
 #include PP_IMPL
+#include "conv_pp1.inc.h"
 #include "conv_small.inc.h"
 
 struct Geo {
@@ -644,6 +645,8 @@ int compute_geo(const ConvDesc& d, Geo& g) {
 }
 
 }  // namespace
+
+int conv1x1_pp_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) { return pp1_try_launch(d, stream, gn_slots_used); }
 
 int conv_tile_n(int Cout) {
   if (Cout % 128 == 0) return 128;

@@ -60,6 +60,8 @@ void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks
 int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr, int* act_done = nullptr);
 // 1x1 GEMM with a stationary activation tile (conv1x1.hip): 0 = launched, 1 = not eligible, <0 = error
 int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
+// 1x1 GEMM in the ping-pong structure (conv_pp1.inc.h: 256 pixels x 256 channels, both operands streamed by DMA): same return convention
+int conv1x1_pp_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
 
 // ---- GroupNorm statistics -> per-(n, channel) affine ----------------------------------------------
 // a[n,c] = rstd * gamma[c] (* (1 + film_scale)), b[n,c] = beta[c] - mean * rstd * gamma[c] (FiLM folded)

@@ -206,6 +206,45 @@ def test_pingpong_conv(case, dtype, rtol, atol):
     torch.testing.assert_close(outs[0], old, rtol=rtol, atol=atol)
 
 
+PP1_CASES = [
+    # B, C0, C1, H, Cout, emb, res      prologue-free 1x1 convs with Cout % 256 == 0 on images of whole 256-pixel tiles => conv1x1_pp_kernel, forced
+    (6, 256, 0, 16, 256, False, True),       # AttentionBlock proj_out: + x (unet.py:389,401), one tile per image
+    (300, 256, 0, 16, 256, False, True),     # more tiles than CUs: the persistent walk, the streams crossing tile boundaries, the counted epilogue window
+    (40, 256, 256, 16, 256, False, False),   # ResBlock skip_connection over a concat (unet.py:318,725): the activation stream switches descriptors half way
+    (33, 256, 128, 16, 256, False, False),   # 384 -> 256: 12 chunks
+    (5, 128, 0, 32, 256, True, False),       # four tiles per image, the minimum of four chunks, per-image embedding in the start values
+    (3, 128, 128, 16, 512, False, True),     # two 256-channel tiles per pixel tile (XCD-paired walk)
+]
+
+
+@pytest.mark.parametrize("case", PP1_CASES)
+@pytest.mark.parametrize("dtype,rtol,atol", [(_lib.MI355_F32, 5e-5, 5e-5), (_lib.MI355_BF16, 3e-2, 3e-2)])
+def test_pingpong_conv1x1(case, dtype, rtol, atol):
+    """conv1x1_pp_kernel (conv_pp1.inc.h) vs F.conv2d(cat(...)) + emb + res, and vs the kernels it replaces (conv_pp = 0)."""
+    from mi355.ops import default_ops as ops
+
+    B, C0, C1, H, Co, use_emb, use_res = case
+    seed = 9500 + hash(case) % 400
+    x = randn(seed, B, C0, H, H) * 1.3 + 0.1
+    x1 = randn(seed + 1, B, C1, H, H) * 0.7 - 0.2 if C1 else None
+    C = C0 + C1
+    sd = synth_state_dict({"weight": (Co, C, 1, 1), "bias": (Co,)}, seed + 2)
+    emb = randn(seed + 3, B, Co) * 0.5 if use_emb else None
+    res = randn(seed + 4, B, Co, H, H) if use_res else None
+    h = x if x1 is None else torch.cat((x, x1), dim=1)
+    ref = F.conv2d(h, sd["weight"], sd["bias"])
+    if emb is not None:
+        ref = ref + emb[:, :, None, None]
+    if res is not None:
+        ref = ref + res
+    kw = dict(dtype=dtype, x1=x1.to(DEV) if x1 is not None else None, emb=emb.to(DEV) if emb is not None else None,
+              res=res.to(DEV) if res is not None else None, res_mode=1)
+    got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=2), **kw).cpu()
+    old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=0), **kw).cpu()
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
+    torch.testing.assert_close(got, old, rtol=rtol, atol=atol)
+
+
 def test_small_tile_conv_concat_residual_emb_fp32():
     """The same epilogue / two-source paths on the plain (non-persistent) kernels: small batches, 8x8 multi-image tiles, 1x1."""
     from mi355.ops import default_ops as ops
