@@ -128,26 +128,65 @@ def self_launch(n, port=0):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-    procs = []
+    import tempfile
+    import time
+
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL across processes)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        # every rank's output goes to a file of its own (a pipe nobody drains can block a child; rank > 0 output is kept for failures)
+        logs.append(tempfile.TemporaryFile(mode="w+"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=logs[-1], stderr=subprocess.STDOUT if r else None))
+    # Poll ALL children: if any rank dies early (import error, GPU fault, out of memory) the others would sit in the rendezvous or in a
+    # collective until the process-group timeout; on the first non-zero exit the siblings are terminated (they are plain children of this
+    # process: terminate / kill by handle, nothing is matched by pattern) and the failure is reported with the failed ranks' output.
+    rcs = [None] * n
+    failed, first_bad = False, 0
+    while any(rc is None for rc in rcs):
+        for r, pr in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = pr.poll()
+                if rcs[r] not in (None, 0):
+                    failed, first_bad = True, first_bad or rcs[r]
+        if failed:
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    pr.terminate()
+            t_end = time.time() + 10
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = pr.wait(timeout=max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        rcs[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    logs[0].seek(0)
+    out0 = logs[0].read()
     if out0:
         sys.stdout.write(out0)
         sys.stdout.flush()
-    worst = max(rcs, key=lambda c: (c != 0, abs(c)))
+    worst = first_bad or max(rcs, key=lambda c: (c != 0, abs(c)))   # the rank that failed by itself, not the siblings this parent then terminated
     if worst:
         sys.stderr.write(f"bench.py: child exit codes {rcs}\n")
+        for r in range(1, n):
+            logs[r].seek(0)
+            tail = logs[r].read()[-2000:]
+            if tail.strip():
+                sys.stderr.write(f"---- rank {r} output (tail) ----\n{tail}\n")
+    for f in logs:
+        f.close()
     return worst
 
 
 def dry_run(a, mdist):
     """The N > 1 path up to the first GPU call: environment, process group (gloo), this rank's shard of the global batch."""
+    if os.environ.get("MI355_BENCH_TEST_DIE_RANK", "") == os.environ.get("RANK", "?"):   # tests only: a rank that dies before the rendezvous
+        sys.stderr.write("dying on request\n")
+        return 7
     rank, world, local = mdist.init_from_env(backend="gloo")
     ok = world == a.gpus and 0 <= rank < world and local == rank
     B = (a.batch or WORKLOADS[a.workload]["batch"])

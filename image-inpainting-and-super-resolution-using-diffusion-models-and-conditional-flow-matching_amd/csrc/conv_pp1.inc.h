@@ -13,16 +13,24 @@
 //     stores of tile i overlap the input stream of tile i + 1 (with one tile per CU - B = 256 at 16x16 - they overlap its own tail only).
 // Ordering rules and the tick diagram are conv_pp.inc.h's (T = chunks per tile).
 namespace pp1 {
-constexpr int BM = 256, BN = 256, TAPB = 256 * 64;          // one chunk of either operand: 256 rows x 64 B = 16 KB = 16 pieces
 constexpr int NRING = 4, AHEAD = 3;
-constexpr int OFF_A = 0, OFF_B = NRING * TAPB;              // 65,536
-constexpr size_t LDS_BYTES = 2 * NRING * (size_t)TAPB;      // 131,072 B
-constexpr int OPS = 4;                                      // DMA pieces a wave issues per L segment: 2 of the weights, 2 of the activations
+// WIDE = 1: tile 256 pixels x 256 channels, waves 2 (pixels) x 4 (channels); WIDE = 0: 512 pixels x 128 channels, waves 4 x 2 (the 128-channel
+// outputs of the 32x32 level).  A wave tile is 128 pixels x 64 channels either way.
+template <int WIDE> struct Cfg {
+  static constexpr int BM = WIDE ? 256 : 512, BN = WIDE ? 256 : 128;
+  static constexpr int TAPA = BM * 64, TAPB = BN * 64;                  // one chunk of the activations / of the weights
+  static constexpr int PA = BM / 16 / 8, PB = BN / 16 / 8;              // 1-KB DMA pieces per wave and step: 2 + 2 / 4 + 1
+  static constexpr int OPS = PA + PB;
+  static constexpr int OFF_A = 0, OFF_B = NRING * TAPA;
+  static constexpr size_t LDS_BYTES = NRING * ((size_t)TAPA + TAPB);    // 131,072 / 163,840 B
+};
 }  // namespace pp1
 
-template <typename T>
+template <typename T, int WIDE>
 __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_mt, int n_nt) {
   using namespace pp1;
+  using G = Cfg<WIDE>;
+  constexpr int BM = G::BM, BN = G::BN, TAPA = G::TAPA, TAPB = G::TAPB, PA = G::PA, PB = G::PB, OPS = G::OPS, OFF_A = G::OFF_A, OFF_B = G::OFF_B;
   using E = Elem<T>;
   constexpr int CHUNK = E::CHUNK, ESZ = sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -30,7 +38,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
   const int lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave8 >> 2;                 // 0: waves 0-3, 1: waves 4-7 (the second wave of each SIMD), one tick behind
-  const int wm = grp, wn = wave8 & 3;         // pixels 128 wm .. 128 wm + 127 of the tile, channels 64 wn .. 64 wn + 63
+  const int wm = WIDE ? grp : wave8 >> 1, wn = WIDE ? wave8 & 3 : wave8 & 1;   // pixels 128 wm .. 128 wm + 127 of the tile, channels 64 wn .. 64 wn + 63
   const int lr = lane & 15, lq = lane >> 4;
   const int TT = p.nchunks;                   // steps per tile (a multiple of 4: the launcher)
   const int HW = p.Ho * p.Wo;                 // a multiple of 256 (the launcher): a tile never straddles two images
@@ -58,12 +66,13 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
   // ---------------- DMA streams (three steps ahead of the multiplication, continuous across tiles) ----------------
   // Weights: chunk c of a 256-channel tile = tile (2 nt + g, c) of the packed image ([nt128][chunk][128 rows][64 B], rows already XOR-swizzled:
   // the LDS image) for g = 0, 1: 16 pieces of 1 KB; wave w moves pieces 2 w, 2 w + 1 (group g: half g); piece j lands at ring slot + 1024 j.
-  auto ws_base = [&](int t) { int mt, nt; decode(t, mt, nt); return (uint32_t)((2 * nt + grp) * TT) * 8192u; };
+  // (WIDE = 0: the 128-channel tile is one packed tile of 8 pieces, wave w moves piece w)
+  auto ws_base = [&](int t) { int mt, nt; decode(t, mt, nt); return (uint32_t)((WIDE ? 2 * nt + grp : nt) * TT) * 8192u; };
   uint32_t ws_soff = ws_base(t_first);
-  const uint32_t wvo0 = (uint32_t)(((2 * wave8) & 7) * 1024 + lane * 16), wvo1 = wvo0 + 1024u;
+  const uint32_t wvo0 = (uint32_t)((WIDE ? (2 * wave8) & 7 : wave8) * 1024 + lane * 16);
   // Activations: piece j = pixels 16 j .. 16 j + 15 of the tile x 64 B; lane l lands at slot l & 3 of pixel 16 j + (l >> 2), so the slot swizzle
   // (by the pixel index) goes into the per-lane SOURCE address.  Wave w moves pieces 2 w, 2 w + 1.
-  uint32_t pvo0[2], pvo1[2];             // per-lane source offsets of this wave's two pieces, for the tile whose chunks are being streamed
+  uint32_t pvo0[PA], pvo1[PA];           // per-lane source offsets of this wave's pieces, for the tile whose chunks are being streamed
   auto ps_setup = [&](int t) {
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));   // (opaque: see conv_pp.inc.h ps_setup)
@@ -71,8 +80,8 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
     int mt, nt;
     decode(t, mt, nt);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int px = 16 * (2 * wave8 + q) + (ln >> 2);
+    for (int q = 0; q < PA; ++q) {
+      const int px = 16 * (PA * wave8 + q) + (ln >> 2);
       const uint32_t pix = (uint32_t)(mt * BM + px);
       const uint32_t fq = (uint32_t)(((ln & 3) ^ ((px >> 1) & 3)) * 16);
       pvo0[q] = pix * (uint32_t)(p.C0 * ESZ) + fq;
@@ -81,23 +90,25 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
   };
   ps_setup(t_first);
   int s_chunk = 0;                       // chunk of the streamed tile the next L segment fetches
-  auto issue = [&](auto ringc) {         // the stream's next step: weights, then activations (4 pieces)
+  auto issue = [&](auto ringc) {         // the stream's next step: weights, then activations
     constexpr int ring = decltype(ringc)::value;
-    char* dw = smem + OFF_B + ring * TAPB + (2 * wave8) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)dw, 16, wvo0, ws_soff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(dw + 1024), 16, wvo1, ws_soff, 0, 0);
+    char* dw = smem + OFF_B + ring * TAPB + (PB * wave8) * 1024;
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(dw + q * 1024), 16, wvo0 + q * 1024u, ws_soff, 0, 0);
     ws_soff += 8192u;
     const int cb = s_chunk * CHUNK;
     const bool first = cb < p.C0;
     const uint32_t so = (uint32_t)((first ? cb : cb - p.C0) * ESZ);
-    char* da = smem + OFF_A + ring * TAPB + (2 * wave8) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (__attribute__((address_space(3))) void*)da, 16, first ? pvo0[0] : pvo1[0], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (__attribute__((address_space(3))) void*)(da + 1024), 16, first ? pvo0[1] : pvo1[1], so, 0, 0);
+    char* da = smem + OFF_A + ring * TAPA + (PA * wave8) * 1024;
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (__attribute__((address_space(3))) void*)(da + q * 1024), 16, first ? pvo0[q] : pvo1[q], so, 0, 0);
     ++s_chunk;
   };
 
   // ---------------- fragment addresses (bases made opaque per step: see conv_pp.inc.h) ----------------
-  int a_base = OFF_A + (wm * 128 + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));   // + ring * TAPB + mi * 1024 as immediates
+  int a_base = OFF_A + (wm * 128 + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));   // + ring * TAPA (added per step: beyond the 16-bit immediate when WIDE = 0) + mi * 1024
   int b_base = OFF_B + (wn * 64 + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));    // + ring * TAPB + ni * 1024
 
   constexpr bool PAIR = E::DTYPE == 1;
@@ -149,12 +160,12 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
       const bool last_of_tile = lastq && S == 3;
       u32x4 af[8], bf[NI];
       {
-        int ab = a_base, bb = b_base;
+        int ab = a_base + S * TAPA, bb = b_base;
         asm volatile("" : "+v"(ab), "+v"(bb));
         const char* ap = smem + ab;
         const char* bp = smem + bb;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(ap + S * TAPB + mi * 1024);
+        for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(ap + mi * 1024);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const u32x4*>(bp + S * TAPB + ni * 1024);
       }
@@ -258,9 +269,9 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
     auto epi = [&](auto resc, auto gnc) { epi_half(IC<0>(), resc, gnc); epi_half(IC<1>(), resc, gnc); };
     if (p.res_mode != RES_NONE) { if (!do_gn) epi(IC<1>(), IC<0>()); else epi(IC<1>(), IC<1>()); }
     else { if (!do_gn) epi(IC<0>(), IC<0>()); else epi(IC<0>(), IC<1>()); }
-    if (do_gn) {   // slot = (256-pixel tile of the image, 128-pixel half); quads of this wave's 64 channels
+    if (do_gn) {   // slot = (pixel tile of the image, 128-pixel part); quads of this wave's 64 channels
       const int rem = (m0 - n0 * HW) / BM;
-      gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * 2 + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * 64) >> 2)) * 2, lq, lr);
+      gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * (BM / 128) + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * 64) >> 2)) * 2, lq, lr);
     }
     acc_init();
     if constexpr (!PAIR) pp_wait_vm<0>();
@@ -272,15 +283,28 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
 }
 
 // 0 = launched, 1 = not eligible (the caller goes on to the stationary-tile / generic kernels), < 0 = error.  mode: mi355_debug_config::conv_pp.
+template <typename T, int WIDE>
+static int pp1_launch(const ConvKArgs& a, int n_mt, int n_nt, hipStream_t stream) {
+  if (int rc = mi355_allow_big_lds(conv1x1_pp_kernel<T, WIDE>, "conv1x1 (ping-pong)")) return rc;
+  const int ntp = ((n_mt + 7) / 8) * 8 * n_nt, ncu = ws_num_cus();
+  const int grid = ntp < ncu ? ntp : ncu;   // one persistent workgroup per CU
+  hipLaunchKernelGGL((conv1x1_pp_kernel<T, WIDE>), dim3(grid), dim3(512), pp1::Cfg<WIDE>::LDS_BYTES, stream, a, n_mt, n_nt);
+  return 0;
+}
+
+// 0 = launched, 1 = not eligible (the caller goes on to the stationary-tile / generic kernels), < 0 = error.  mode: mi355_debug_config::conv_pp.
 static int pp1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
   const int CH = d.dtype == 0 ? 16 : 32, esz = d.dtype == 0 ? 4 : 2;
   if (!K.conv_pp || d.ks != 1 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.pro_a) return 1;
-  if (d.Cout % pp1::BN != 0 || d.C0 % CH != 0 || d.C1 % CH != 0 || conv_tile_n(d.Cout) != 128) return 1;
+  if (d.Cout % 128 != 0 || d.C0 % CH != 0 || d.C1 % CH != 0 || conv_tile_n(d.Cout) != 128) return 1;
+  const int wide = d.Cout % 256 == 0;
+  const int BM = wide ? 256 : 512, BN = wide ? 256 : 128;
   const int Cin = d.C0 + d.C1, nchunks = Cin / CH, HW = d.Hs * d.Ws;
-  if (nchunks < 4 || (nchunks & 3) || (HW % pp1::BM) != 0) return 1;
+  // (four chunks: the old stationary-tile kernel ties - 128 -> 256 at 16x16: 13.4 vs 13.9 us - and stays)
+  if (nchunks < 8 || (nchunks & 3) || (HW % BM) != 0) return 1;
   if (d.res && d.res_mode != RES_SAME) return 1;
-  const int n_mt = (int)((long)d.N * HW / pp1::BM), n_nt = d.Cout / pp1::BN;
+  const int n_mt = (int)((long)d.N * HW / BM), n_nt = d.Cout / BN;
   if (K.conv_pp < 2 && n_mt * n_nt < ws_num_cus()) return 1;
   ConvKArgs a{};
   a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = nchunks;
@@ -295,16 +319,12 @@ static int pp1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_u
                 "conv1x1: a tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb; a.obytes = (uint32_t)ob; a.rbytes = d.res ? (uint32_t)ob : 0u;
   a.ablate = K.conv_ablate; a.err = d.err; a.spin_limit = 1;
-  const int slots = 2 * (HW / pp1::BM);
+  const int slots = HW / 128;               // (pixel tile of the image, 128-pixel part)
   if (d.gn_stats && slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = slots; }
   int rc;
-  if (d.dtype == 0) rc = mi355_allow_big_lds(conv1x1_pp_kernel<float>, "conv1x1 (ping-pong)");
-  else rc = mi355_allow_big_lds(conv1x1_pp_kernel<bf16>, "conv1x1 (ping-pong)");
+  if (d.dtype == 0) rc = wide ? pp1_launch<float, 1>(a, n_mt, n_nt, stream) : pp1_launch<float, 0>(a, n_mt, n_nt, stream);
+  else rc = wide ? pp1_launch<bf16, 1>(a, n_mt, n_nt, stream) : pp1_launch<bf16, 0>(a, n_mt, n_nt, stream);
   if (rc) return rc;
-  const int ntp = ((n_mt + 7) / 8) * 8 * n_nt, ncu = ws_num_cus();
-  const int grid = ntp < ncu ? ntp : ncu;   // one persistent workgroup per CU
-  if (d.dtype == 0) hipLaunchKernelGGL(conv1x1_pp_kernel<float>, dim3(grid), dim3(512), pp1::LDS_BYTES, stream, a, n_mt, n_nt);
-  else hipLaunchKernelGGL(conv1x1_pp_kernel<bf16>, dim3(grid), dim3(512), pp1::LDS_BYTES, stream, a, n_mt, n_nt);
   MI355_CHECK_HIP(hipGetLastError());
   if (gn_slots_used) *gn_slots_used = a.gn_slots;
   return 0;

@@ -53,10 +53,10 @@ constexpr int BN = 128, WTILE = BN * 64, WIT = 3 * WTILE / (256 * 16);      // 6
 constexpr int CBUF = BN * 4;                                                // bias + emb of one tile's channels (f32)
 constexpr int NPLANES = 3, NWBUF = 4;                                        // patch planes / weight row buffers
 constexpr int XBUF = 2 * 4 * 16 * 8;                                        // fused-GroupNorm epilogue: the two 8-row halves of a tile exchange their group sums
-constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE + 2 * CBUF + 32 + 16 + XBUF;   // 161,568 B (+ the eight counters)
+constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE + 2 * CBUF + 32 + 16 + 16 + XBUF;   // 161,568 B (+ the eight counters)
 // Counter polls are bounded (p.spin_limit, default 1 << 22 polls of >= 64 cycles: seconds): a protocol bug or a wave that never arrives
-// ends in MI355_ERR_TIMEOUT instead of a hung GPU.  A wait that gives up ORs 1 into the launch's error word (p.err; cold path inside
-// the poll's asm block) and the wave goes on: the tile is wrong, the grid still drains.
+// ends in MI355_ERR_TIMEOUT instead of a hung GPU.  A wait that gives up stores 1 into the launch's error word (p.err; cold path inside
+// the poll's asm block), every later wait of that wave polls once, and the wave goes on: the tile is wrong, the grid drains at once.
 }  // namespace ws
 
 // GN affine (+ SiLU) of one 16-byte fragment.  bf16: fp32 math on element PAIRS (v_pk_fma/mul/add_f32: two elements per VALU
@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   uint32_t* c_prod = reinterpret_cast<uint32_t*>(cbuf + 2 * CBUF);   // [4]: kernel rows staged by loader wave w
   uint32_t* c_cons = c_prod + 4;                                     // [4]: kernel rows read by consumer wave w
   uint32_t* c_xch = c_cons + 4;                                      // [4]: tiles whose group sums consumer wave w has published (fused-GroupNorm epilogue)
-  char* xbuf = reinterpret_cast<char*>(c_xch + 4);                   // [2 parity][4 waves][16 quads] x (sum, sum of squares)
+  // c_prod[12]: the workgroup's give-up flag (see wait_ge); c_prod[13 .. 15]: pad
+  char* xbuf = reinterpret_cast<char*>(c_xch + 8);                   // [2 parity][4 waves][16 quads] x (sum, sum of squares)
 
   const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   int t_first = (int)blockIdx.x - (int)gridDim.x;
   t_first = next_valid(t_first);
   if (t_first >= ntp) return;        // whole workgroup leaves together: no barrier is ever reached
-  if (threadIdx.x < 12) c_prod[threadIdx.x] = 0u;
+  if (threadIdx.x < 16) c_prod[threadIdx.x] = 0u;
   if constexpr ((WS_ABLATE & 2048) != 0) {   // consumers-alone experiment: random bf16 operands in [0.5, 1) of either sign (zeros would raise the clock)
     for (int i = threadIdx.x; i < (NPLANES * PLANE + NWBUF * 3 * WTILE) / 16; i += 512) {
       uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
@@ -153,41 +154,58 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   // outstanding fragment reads, which it would have to wait for before the next row's MFMAs anyway.
   // the launch's error word (conv_launch always passes one: the caller's, or a scratch word of the workspace)
   const __attribute__((address_space(1))) uint32_t* errp = (const __attribute__((address_space(1))) uint32_t*)p.err;
-  auto wait_ge = [&](const uint32_t* cp, uint32_t target) {
-    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)cp;
-    uint32_t v0, v1, v2, v3; int sv, spins = p.spin_limit;
-    asm volatile(
-        "1:\n\t"
-        "ds_read_b32 %0, %6\n\t"
-        "ds_read_b32 %1, %6 offset:4\n\t"
-        "ds_read_b32 %2, %6 offset:8\n\t"
-        "ds_read_b32 %3, %6 offset:12\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_min_u32 %0, %0, %1\n\t"
-        "v_min_u32 %2, %2, %3\n\t"
-        "v_min_u32 %0, %0, %2\n\t"
-        "s_nop 0\n\t"
-        "v_readfirstlane_b32 %4, %0\n\t"
-        "s_cmp_ge_u32 %4, %7\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_sub_u32 %5, %5, 1\n\t"
-        "s_cmp_eq_u32 %5, 0\n\t"
-        "s_cbranch_scc1 4f\n\t"
-        "s_sleep " WS_STR(WS_LSLEEP) "\n\t"
-        "s_branch 1b\n\t"
-        "4:\n\t"                                  // gave up: flag the launch (one lane, no return value), then go on
-        "s_cmp_eq_u64 %8, 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "v_mov_b32 %0, 0\n\t"
-        "v_mov_b32 %1, 1\n\t"
-        "global_atomic_or %0, %1, %8\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "2:"
-        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&s"(sv), "+s"(spins)
-        : "v"(a), "s"(target), "s"(errp)
+  // The give-up is STICKY per workgroup: the first wait that expires sets a flag word in LDS (c_prod[12]); every poll loop looks at it before
+  // it sleeps (slow path only) and leaves at once when it is set, so a flagged launch drains in microseconds (the default limit is about
+  // a second per wait, a workgroup runs ~190 waits per tile, and sampler loops have dozens of launches queued behind).  FO = byte
+  // offset of the flag from the counter row the wait polls (48 from c_prod, 32 from c_cons): an immediate, no register.
+  // (two plain lambdas from one macro: as a generic lambda over the offset hipcc rejects the capture of the address-space-qualified errp)
+  // (in the slow path: the flag read = another wait of this workgroup has given up, leave at once; label 4 = gave up: set the workgroup's flag and
+  //  flag the launch - one lane, a plain system-scope store: the word is host memory and only bit 0 is ever set, no PCIe AtomicOps needed - then go on)
+#define WS_WAIT_GE_BODY(FO_) \
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)cp; \
+    uint32_t v0, v1, v2, v3; int sv, spins = p.spin_limit; \
+    asm volatile( \
+        "1:\n\t" \
+        "ds_read_b32 %[v0], %[a]\n\t" \
+        "ds_read_b32 %[v1], %[a] offset:4\n\t" \
+        "ds_read_b32 %[v2], %[a] offset:8\n\t" \
+        "ds_read_b32 %[v3], %[a] offset:12\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_min_u32 %[v0], %[v0], %[v1]\n\t" \
+        "v_min_u32 %[v2], %[v2], %[v3]\n\t" \
+        "v_min_u32 %[v0], %[v0], %[v2]\n\t" \
+        "s_nop 0\n\t" \
+        "v_readfirstlane_b32 %[sv], %[v0]\n\t" \
+        "s_cmp_ge_u32 %[sv], %[tg]\n\t" \
+        "s_cbranch_scc1 2f\n\t" \
+        "s_sub_u32 %[sp], %[sp], 1\n\t" \
+        "s_cmp_eq_u32 %[sp], 0\n\t" \
+        "s_cbranch_scc1 4f\n\t" \
+        "ds_read_b32 %[v1], %[a] offset:%[fo]\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_readfirstlane_b32 %[sv], %[v1]\n\t" \
+        "s_cmp_lg_u32 %[sv], 0\n\t" \
+        "s_cbranch_scc1 2f\n\t" \
+        "s_sleep " WS_STR(WS_LSLEEP) "\n\t" \
+        "s_branch 1b\n\t" \
+        "4:\n\t" \
+        "s_mov_b64 exec, 1\n\t" \
+        "v_mov_b32 %[v1], 1\n\t" \
+        "ds_write_b32 %[a], %[v1] offset:%[fo]\n\t" \
+        "s_cmp_eq_u64 %[err], 0\n\t" \
+        "s_cbranch_scc1 5f\n\t" \
+        "v_mov_b32 %[v0], 0\n\t" \
+        "global_store_dword %[v0], %[v1], %[err] sc0 sc1\n\t" \
+        "5:\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
+        "2:" \
+        : [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [sv] "=&s"(sv), [sp] "+s"(spins) \
+        : [a] "v"(a), [tg] "s"(target), [err] "s"(errp), [fo] "i"(FO_) \
         : "scc", "memory");
-  };
+  auto wait_ge_prod = [&](const uint32_t* cp, uint32_t target) { WS_WAIT_GE_BODY(48) };   // polls c_prod
+  auto wait_ge_cons = [&](const uint32_t* cp, uint32_t target) { WS_WAIT_GE_BODY(32) };   // polls c_cons
+#undef WS_WAIT_GE_BODY
+
   // The consumers' row hand-over, split so that the poll's LDS round trip hides behind a half-tap of MFMAs: `poll_issue` reads the
   // four producer counters (before the MFMAs of step 4), `release_acquire` (step 5) releases the finished row and only spins if
   // the early values were not there yet.
@@ -206,39 +224,46 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     int sv, spins = p.spin_limit;
     asm volatile(
         "s_mov_b64 exec, 1\n\t"
-        "ds_add_u32 %7, %8\n\t"
+        "ds_add_u32 %[am], %[one]\n\t"
         "s_mov_b64 exec, -1\n\t"
         "s_branch 3f\n\t"
         "1:\n\t"
-        "ds_read_b32 %0, %6\n\t"
-        "ds_read_b32 %1, %6 offset:4\n\t"
-        "ds_read_b32 %2, %6 offset:8\n\t"
-        "ds_read_b32 %3, %6 offset:12\n\t"
+        "ds_read_b32 %[v0], %[a]\n\t"
+        "ds_read_b32 %[v1], %[a] offset:4\n\t"
+        "ds_read_b32 %[v2], %[a] offset:8\n\t"
+        "ds_read_b32 %[v3], %[a] offset:12\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "3:\n\t"
-        "v_min_u32 %0, %0, %1\n\t"
-        "v_min_u32 %2, %2, %3\n\t"
-        "v_min_u32 %0, %0, %2\n\t"
+        "v_min_u32 %[v0], %[v0], %[v1]\n\t"
+        "v_min_u32 %[v2], %[v2], %[v3]\n\t"
+        "v_min_u32 %[v0], %[v0], %[v2]\n\t"
         "s_nop 0\n\t"
-        "v_readfirstlane_b32 %4, %0\n\t"
-        "s_cmp_ge_u32 %4, %9\n\t"
+        "v_readfirstlane_b32 %[sv], %[v0]\n\t"
+        "s_cmp_ge_u32 %[sv], %[tg]\n\t"
         "s_cbranch_scc1 2f\n\t"
-        "s_sub_u32 %5, %5, 1\n\t"
-        "s_cmp_eq_u32 %5, 0\n\t"
+        "s_sub_u32 %[sp], %[sp], 1\n\t"
+        "s_cmp_eq_u32 %[sp], 0\n\t"
         "s_cbranch_scc1 4f\n\t"
+        "ds_read_b32 %[v1], %[a] offset:48\n\t"   // (cp = c_prod here) another wait of this workgroup has given up: leave at once
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[sv], %[v1]\n\t"
+        "s_cmp_lg_u32 %[sv], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
         "s_sleep " WS_STR(WS_CSLEEP) "\n\t"
         "s_branch 1b\n\t"
         "4:\n\t"
-        "s_cmp_eq_u64 %10, 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
         "s_mov_b64 exec, 1\n\t"
-        "v_mov_b32 %0, 0\n\t"
-        "v_mov_b32 %1, 1\n\t"
-        "global_atomic_or %0, %1, %10\n\t"
+        "v_mov_b32 %[v1], 1\n\t"
+        "ds_write_b32 %[a], %[v1] offset:48\n\t"
+        "s_cmp_eq_u64 %[err], 0\n\t"
+        "s_cbranch_scc1 5f\n\t"
+        "v_mov_b32 %[v0], 0\n\t"
+        "global_store_dword %[v0], %[v1], %[err] sc0 sc1\n\t"
+        "5:\n\t"
         "s_mov_b64 exec, -1\n\t"
         "2:"
-        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&s"(sv), "+s"(spins)
-        : "v"(a), "v"(am), "v"(one), "s"(target), "s"(errp)
+        : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [v3] "+v"(v3), [sv] "=&s"(sv), [sp] "+s"(spins)
+        : [a] "v"(a), [am] "v"(am), [one] "v"(one), [tg] "s"(target), [err] "s"(errp)
         : "scc", "memory");
   };
   auto bump = [&](uint32_t* cp) {
@@ -352,7 +377,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     };
     int R = 0;
     auto acquire_free = [&]() {
-      if (R >= NWBUF - 1) wait_ge(c_cons, (uint32_t)(R - (NWBUF - 2)));
+      if (R >= NWBUF - 1) wait_ge_cons(c_cons, (uint32_t)(R - (NWBUF - 2)));
     };
     // accumulator start values (bias + timestep embedding) of a tile's 128 channels, staged in LDS for the consumers: loaded at the
     // start of a tile's LAST chunk, committed at its end (the compiler's wait for the two loads then finds them long complete)
@@ -533,7 +558,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     // R + 1 into the buffer row R + 1 - NWBUF = R - 3 was read from: both are free once the consumers have released row R - 3.
     int R = 0;
     auto acquire_free = [&]() {
-      if (R >= NWBUF - 1) wait_ge(c_cons, (uint32_t)(R - (NWBUF - 2)));
+      if (R >= NWBUF - 1) wait_ge_cons(c_cons, (uint32_t)(R - (NWBUF - 2)));
     };
 
     // ---- accumulator start values of a tile: 128 channels, 4 per thread of the first half-wave ----
@@ -748,7 +773,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       __builtin_amdgcn_sched_barrier(0);
     };
 
-    if constexpr (!(WS_ABLATE & 2048)) wait_ge(c_prod, 1u);               // kernel row 0 of the first tile is staged
+    if constexpr (!(WS_ABLATE & 2048)) wait_ge_prod(c_prod, 1u);               // kernel row 0 of the first tile is staged
     STAMP(5)
     read_a(IC<0>(), IC<0>(), IC<0>());
     read_b(IC<0>(), IC<0>());
@@ -987,7 +1012,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       }
       STAMP(7)
       if (t_next < ntp) {
-        if constexpr (!(WS_ABLATE & 2048)) wait_ge(c_prod, rowc + 2u);
+        if constexpr (!(WS_ABLATE & 2048)) wait_ge_prod(c_prod, rowc + 2u);
         ++rowc;
         advance_row();
         read_a(IC<0>(), IC<0>(), IC<0>());

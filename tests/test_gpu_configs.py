@@ -214,6 +214,10 @@ PP1_CASES = [
     (33, 256, 128, 16, 256, False, False),   # 384 -> 256: 12 chunks
     (5, 128, 0, 32, 256, True, False),       # four tiles per image, the minimum of four chunks, per-image embedding in the start values
     (3, 128, 128, 16, 512, False, True),     # two 256-channel tiles per pixel tile (XCD-paired walk)
+    # 128-channel outputs: 512-pixel x 128-channel tiles (waves 4 x 2), images of whole 512-pixel tiles
+    (5, 256, 128, 32, 128, False, False),    # output_blocks skip_connection 384 -> 128 at 32x32 (unet.py:318): two tiles per image, 12 chunks
+    (140, 256, 0, 32, 128, True, True),      # more tiles than CUs, embedding + residual
+    (3, 128, 128, 32, 384, False, True),     # three 128-channel tiles per pixel tile
 ]
 
 

@@ -440,6 +440,17 @@ def test_engine_error_word_and_diagnostic_switches():
     with pytest.raises(MI355BackendError):
         eng.check(clear=True)
     eng.check()                                                       # cleared
+    # the same with the DEFAULT limit (4M polls, about a second for the first wait that expires): the give-up is sticky per workgroup, so
+    # the flagged launch - and the launches queued behind it - drain at once instead of spending a second in each of ~190 waits per tile
+    import time
+    net, eng = run("bf16", conv_ablate=32)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    eng.forward(x, t)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 20.0, time.time() - t0
+    with pytest.raises(MI355BackendError, match="counter wait"):
+        eng.check(clear=True)
     _, e0 = run()
     base = e0.forward(x, t).cpu()
     torch.cuda.synchronize(); e0.check()

@@ -222,6 +222,14 @@ def test_bench_self_launch_dry_run():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0
+    # a rank that dies before the rendezvous: the parent notices, ends the sibling (which would sit in the rendezvous until the process-group
+    # timeout), reports the exit codes with the dead rank's output and returns its code - within seconds
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, MI355_BENCH_TEST_DIE_RANK="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 7 and time.time() - t0 < 120, (r.returncode, time.time() - t0, r.stderr[-500:])
+    assert "child exit codes" in r.stderr and "dying on request" in r.stderr
 
 
 def test_product_never_imports_oracle():
