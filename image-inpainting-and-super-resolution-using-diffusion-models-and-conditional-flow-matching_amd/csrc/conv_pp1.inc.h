@@ -72,7 +72,10 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
   const uint32_t wvo0 = (uint32_t)((WIDE ? (2 * wave8) & 7 : wave8) * 1024 + lane * 16);
   // Activations: piece j = pixels 16 j .. 16 j + 15 of the tile x 64 B; lane l lands at slot l & 3 of pixel 16 j + (l >> 2), so the slot swizzle
   // (by the pixel index) goes into the per-lane SOURCE address.  Wave w moves pieces 2 w, 2 w + 1.
-  uint32_t pvo0[PA], pvo1[PA];           // per-lane source offsets of this wave's pieces, for the tile whose chunks are being streamed
+  // (sized by a literal, PA <= 4 used: as `uint32_t pvo0[PA]` - a size that depends on the template parameter - hipcc 7.2's HOST pass silently
+  //  drops the kernel's stub once the DMA builtin reads the array inside a lambda, and the library fails to load with an undefined symbol;
+  //  tests/test_abi.py loads the library on the CPU)
+  uint32_t pvo0[4], pvo1[4];             // per-lane source offsets of this wave's pieces, for the tile whose chunks are being streamed
   auto ps_setup = [&](int t) {
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));   // (opaque: see conv_pp.inc.h ps_setup)
