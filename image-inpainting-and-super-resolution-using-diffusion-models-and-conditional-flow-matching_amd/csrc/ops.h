@@ -62,6 +62,8 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = null
 int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
 // 1x1 GEMM in the ping-pong structure (conv_pp1.inc.h: 256 pixels x 256 channels, both operands streamed by DMA): same return convention
 int conv1x1_pp_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
+// the network's last conv (GN + SiLU prologue, <= 4 output channels, NCHW fp32) as a streaming kernel (conv_edge.hip): same convention
+int conv_out_try_launch(const ConvDesc& d, hipStream_t stream);
 
 // ---- GroupNorm statistics -> per-(n, channel) affine ----------------------------------------------
 // a[n,c] = rstd * gamma[c] (* (1 + film_scale)), b[n,c] = beta[c] - mean * rstd * gamma[c] (FiLM folded)

@@ -105,6 +105,24 @@ def test_gn_silu_conv_fused(ops, silu, dtype, rtol, atol):
         torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("dtype,rtol,atol", [(_lib.MI355_F32, 5e-5, 5e-5), (_lib.MI355_BF16, 3e-2, 3e-2)])
+def test_out_conv_streaming_kernel(ops, dtype, rtol, atol):
+    """UNetModel.out = GroupNorm32 -> SiLU -> conv3x3 to <= 4 channels, NCHW fp32 (unet.py:702-706) on the streaming kernel of conv_edge.hip
+    (conv_edge bit 0) and on the generic tile kernel it replaces: whole images, ragged 20 x 28 images (partial tiles, zero padding applied
+    AFTER the activation), 256 input channels (two fragment groups per pixel in fp32), out_channels 1 .. 4."""
+    for (B, C, H, W, Co) in [(5, 128, 32, 32, 3), (3, 128, 20, 28, 3), (2, 256, 16, 16, 1), (2, 128, 64, 64, 4), (300, 128, 8, 8, 2),
+                             (70, 64, 32, 32, 3), (1, 64, 16, 16, 3), (2, 128, 128, 128, 3)]:   # 64 channels: the fp32 build's counted path; one tile; many tiles per workgroup
+        x = randn(300 + C + H, B, C, H, W) * 1.7 + 0.3
+        sd = synth_state_dict({"in_layers.0.weight": (C,), "in_layers.0.bias": (C,), "weight": (Co, C, 3, 3), "bias": (Co,)}, C + Co)
+        h = F.silu(unet_ref.group_norm32(x, sd["in_layers.0.weight"], sd["in_layers.0.bias"]))
+        ref = F.conv2d(h, sd["weight"], sd["bias"], padding=1)
+        gn = (sd["in_layers.0.weight"].to(DEV), sd["in_layers.0.bias"].to(DEV))
+        got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], gn=gn, gn_silu=True, dtype=dtype, debug=_lib.debug_config(conv_edge=1)).cpu()
+        old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], gn=gn, gn_silu=True, dtype=dtype, debug=_lib.debug_config(conv_edge=0)).cpu()
+        torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
+        torch.testing.assert_close(got, old, rtol=rtol, atol=atol)
+
+
 @pytest.mark.parametrize("dtype,tol", [(_lib.MI355_F32, 2e-5), (_lib.MI355_BF16, 2e-2)])
 def test_qkv_attention(ops, golden, dtype, tol):
     g = golden("attention")

@@ -17,7 +17,19 @@ the paths, and a change of the step count becomes visible.  Reported side by sid
 steps, 50 vs 49 steps, plus the disjoint-x0 floor; the claim to check is "bf16 moves the sample distribution less than dropping
 ONE Euler step does".
 
+Round 4 (task 5): `--split` asks WHICH roundings carry the bf16 mode's per-sample error.  The engine has one element type
+per plan, so the split is made with the two modes it has and with weights / inputs that are rounded to bf16 BEFORE they are handed over:
+  weights            fp32 mode on bf16-rounded conv weights vs fp32 mode on the original ones (all / 3x3 only / 1x1 + qkv + proj only /
+                     first + last conv only): the weight roundings alone;
+  everything else    bf16 mode vs fp32 mode, BOTH on the bf16-rounded weights (exactly representable: the bf16 engine packs them
+                     without error): activation storage, bf16 MFMA operands, bf16 residual trunk - all that is not weight rounding;
+  network input      fp32 mode with the state rounded to bf16 in front of every evaluation (host loop over mi355_unet_forward_t; the Euler
+                     update itself stays fp32): the first conv's input quantisation alone.
+Finer splits of "everything else" (trunk in fp32, fp32 only around conv 0 / out) need kernels with mixed element types, which this
+engine does not have.
+
     python tools/quality_delta.py [--n 10240] [--gain auto|1.0|<float>] [--out gpurun_out/r3_quality_delta.json]
+    python tools/quality_delta.py --split [--n 5120] --out profiles/r4_quality_delta.json
 """
 import argparse
 import json
@@ -41,6 +53,7 @@ def main():
     ap.add_argument("--nfe", type=int, default=50)
     ap.add_argument("--gain", default="auto", help="multiplier of out.2 (weight and bias); auto = 1 / rms of the field at t = 0")
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r3_quality_delta.json"))
+    ap.add_argument("--split", action="store_true", help="round 4: which roundings carry the bf16 mode's error (see the module docstring)")
     a = ap.parse_args()
 
     import evaluation
@@ -88,6 +101,8 @@ def main():
         print(f"{precision} nfe {nfe} seeds {seed0}..: {nb * a.batch} samples in {dt:.1f} s ({nb * a.batch / dt:.0f} img/s)", flush=True)
         return torch.cat(xs), torch.cat(u8s)
 
+    if a.split:
+        return split(a, net, sd, dev, nb, gain, v_rms)
     x16, u16 = sample_set("bf16", 0, a.nfe)
     x32, u32 = sample_set("fp32", 0, a.nfe)
     _, u32b = sample_set("fp32", 100000, a.nfe)          # disjoint x0: same-distribution floor
@@ -125,6 +140,68 @@ def main():
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
     print(json.dumps(res))
+
+
+def split(a, net, sd, dev, nb, gain, v_rms):
+    """Which roundings carry the bf16 mode's per-sample error (module docstring, round 4)."""
+    def rounded(sel):
+        out = dict(sd)
+        for k, v in sd.items():
+            if k.endswith(".weight") and v.dim() >= 3 and sel(k, v):   # conv [Co, Ci, k, k] and qkv / proj_out [Co, Ci, 1]; linears stay fp32 in both modes
+                out[k] = v.to(torch.bfloat16).to(torch.float32)
+        return out
+
+    is3 = lambda k, v: v.dim() == 4 and v.shape[-1] == 3
+    ends = lambda k, v: k in ("input_blocks.0.0.weight", "out.2.weight")
+    sds = {"orig": sd, "w_all": rounded(lambda k, v: True), "w_3x3": rounded(is3), "w_1x1": rounded(lambda k, v: not is3(k, v)),
+           "w_first_last": rounded(ends)}
+    ts = torch.linspace(0, 1, a.nfe + 1).tolist()
+
+    def run(precision, which, nfe=None, round_input=False):
+        net.load_state_dict(sds[which])
+        net.set_precision(precision)
+        eng = net.engine(dev)
+        tt = ts if nfe is None else torch.linspace(0, 1, nfe + 1).tolist()
+        xs = []
+        t0 = time.perf_counter()
+        for k in range(nb):
+            g = torch.Generator(device=dev).manual_seed(k)
+            x = torch.randn(a.batch, 3, 32, 32, device=dev, generator=g)
+            if not round_input:
+                eng.cfm_euler(x, tt)
+            else:   # the same Euler loop on the host: v(t_k, bf16(x_k)); x_{k+1} = x_k + (t_{k+1} - t_k) v in fp32
+                for i in range(len(tt) - 1):
+                    v = eng.forward(x.to(torch.bfloat16).to(torch.float32), float(tt[i]))
+                    x = x + (tt[i + 1] - tt[i]) * v
+            xs.append(x.cpu())
+        torch.cuda.synchronize()
+        print(f"{precision} {which} round_input={round_input} nfe={len(tt) - 1}: {nb * a.batch} samples in {time.perf_counter() - t0:.1f} s", flush=True)
+        return torch.cat(xs)
+
+    rms = lambda d: float(d.pow(2).mean().sqrt())
+    ref = run("fp32", "orig")
+    ref_r = run("fp32", "w_all")
+    rows = {
+        "bf16_mode_vs_fp32_mode (total)": rms(run("bf16", "orig") - ref),
+        "weights_all_rounded (fp32 mode)": rms(ref_r - ref),
+        "weights_3x3_rounded (fp32 mode)": rms(run("fp32", "w_3x3") - ref),
+        "weights_1x1_qkv_proj_rounded (fp32 mode)": rms(run("fp32", "w_1x1") - ref),
+        "weights_first_and_last_conv_rounded (fp32 mode)": rms(run("fp32", "w_first_last") - ref),
+        "everything_but_weights: bf16 mode vs fp32 mode, both on bf16-representable weights": rms(run("bf16", "w_all") - ref_r),
+        "network_input_rounded_each_evaluation (fp32 mode, host Euler loop)": rms(run("fp32", "orig", round_input=True) - ref),
+        f"scale: {a.nfe}_vs_{a.nfe - 1}_steps (fp32 mode)": rms(run("fp32", "orig", nfe=a.nfe - 1) - ref),
+        f"scale: {a.nfe}_vs_{a.nfe - 3}_steps (fp32 mode)": rms(run("fp32", "orig", nfe=a.nfe - 3) - ref),
+        f"scale: {a.nfe}_vs_{a.nfe // 2}_steps (fp32 mode)": rms(run("fp32", "orig", nfe=a.nfe // 2) - ref),
+    }
+    tot, w, act = rows["bf16_mode_vs_fp32_mode (total)"], rows["weights_all_rounded (fp32 mode)"], rows["everything_but_weights: bf16 mode vs fp32 mode, both on bf16-representable weights"]
+    res = {"workload": "cifar10_cfm_euler50 (BASELINE configs[1] net, synthetic seeded weights)", "n_samples": nb * a.batch, "nfe": a.nfe,
+           "field": {"out2_gain": gain, "rms_v_t0": v_rms},
+           "per_sample_rms_of_the_final_state_same_x0": rows,
+           "reading": {"weights_share_of_variance": (w / tot) ** 2, "everything_else_share_of_variance": (act / tot) ** 2,
+                       "sum_in_quadrature_over_total": ((w * w + act * act) ** 0.5) / tot}}
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    json.dump(res, open(a.out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":

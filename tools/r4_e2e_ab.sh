@@ -15,3 +15,4 @@ for rep in 1 2 3; do
   done
 done
 } 2>&1 | tee $O/bench_ab.txt
+if [ -n "$PROFILE" ]; then python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-out $O/per_op.json > /dev/null 2>&1; python tools/show_profile.py $O/per_op.json > $O/per_op.txt; head -45 $O/per_op.txt; fi
