@@ -74,24 +74,38 @@ WORKLOADS = {
 DEFAULT = "cifar10_cfm_euler50_b256"
 
 
-def cpu_baseline(sd, steps_sample=10, batch=64, nfe=50):
-    """fp32 PyTorch-CPU oracle (oracle/unet_ref.py + oracle/cfm_ref.py) on the host cores, bounded sample."""
+def cpu_baseline(sd, steps_sample=10, batch=32, nfe=50, reps=2):
+    """fp32 PyTorch-CPU oracle (oracle/unet_ref.py + oracle/cfm_ref.py) on the host cores, bounded sample (batch 32,
+    >= 2 repetitions).  Each repetition runs `steps_sample` of the `nfe` Euler steps on a fresh batch; every step costs the same
+    (one network evaluation + an axpy), so the rate is scaled to nfe steps.  `value` is the mean of the repetitions."""
     from oracle import cfm_ref, unet_ref
 
     cores = min(os.cpu_count() or 1, 16)  # a 1-GPU box grants a 16-core CPU share; more threads only oversubscribe it
     torch.set_num_threads(cores)
     cfg = unet_ref.UNetConfig(32, 3, 128, 3, 2, (2,), channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
     f = unet_ref.model_fn(sd, cfg)
-    x = torch.randn(batch, 3, 32, 32, generator=torch.Generator().manual_seed(0))
     ts = torch.linspace(0, 1, nfe + 1)[: steps_sample + 1]
-    cfm_ref.euler_trajectory(f, x[:2], ts[:2], keep_all=False)  # warm-up
-    t0 = time.perf_counter()
-    cfm_ref.to_uint8(cfm_ref.euler_trajectory(f, x, ts, keep_all=False))
-    dt = time.perf_counter() - t0
-    ips = batch / (dt * nfe / steps_sample)
-    return {"value": round(ips, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (fp32 PyTorch-CPU restatement) batch {batch}, {steps_sample} of {nfe} Euler steps in {dt:.2f} s, "
-                      f"extrapolated to {nfe} steps; torch.set_num_threads({cores})"}
+    gen = torch.Generator().manual_seed(0)
+    cfm_ref.euler_trajectory(f, torch.randn(2, 3, 32, 32, generator=gen), ts[:2], keep_all=False)  # warm-up
+    secs = []
+    for _ in range(reps):
+        x = torch.randn(batch, 3, 32, 32, generator=gen)
+        t0 = time.perf_counter()
+        cfm_ref.to_uint8(cfm_ref.euler_trajectory(f, x, ts, keep_all=False))
+        secs.append(time.perf_counter() - t0)
+    rates = [batch / (dt * nfe / steps_sample) for dt in secs]
+    cpu_model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(sum(rates) / len(rates), 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "repetitions": [round(r, 4) for r in rates], "cpu": cpu_model,
+            "sample": f"oracle (fp32 PyTorch-CPU restatement) batch {batch}, {reps} repetitions of {steps_sample} of {nfe} Euler steps "
+                      f"({', '.join('%.2f s' % d for d in secs)}), each scaled to {nfe} steps; torch.set_num_threads({cores})"}
 
 
 def make_condition(kind, B, C, S, dev, seed):
@@ -295,7 +309,10 @@ def main():
     eng.profile(x0, tt, cond)  # warm
     recs = eng.profile(x0, tt, cond)
     conv = [r for r in recs if r["kind"] == "conv"]
-    dom = [r for r in conv if r["tile"][0] == 256] or conv
+    k3 = [r for r in conv if r["ks"] == 3 and r["tile"][0] == 256]
+    dom = [r for r in k3 if r["tile"][1] != 256] or k3 or conv    # conv3x3_ws_kernel: 256 px x 128 ch tiles
+    ppk = [r for r in k3 if r["tile"][1] == 256]                  # conv3x3_pp_kernel (round 4): 256 px x 256 ch tiles
+    k1 = [r for r in conv if r["ks"] == 1]
     by = {}
     for r in recs:
         d = by.setdefault(r["kind"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
@@ -306,7 +323,7 @@ def main():
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
     achieved = dfl / (dms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    for pmc_name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
+    for pmc_name in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
         pmc_file = os.path.join(REPO, "profiles", pmc_name)
         if os.path.exists(pmc_file) and a.precision == "bf16" and name == DEFAULT and B == 256:
             ent = json.load(open(pmc_file)).get("kernels", {}).get("conv3x3_ws_kernel")
@@ -314,6 +331,17 @@ def main():
                 traffic = ent["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{pmc_name} (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
                 break
+    def leg(rs, kname, bound):
+        """roofline entry of one more kernel family of the same forward (same accounting as the dominant kernel's)"""
+        if not rs:
+            return None
+        ms, fl, by_ = sum(r["ms"] for r in rs), sum(r["flops"] for r in rs), sum(r["bytes"] for r in rs)
+        e = {"kernel": kname, "launches": len(rs), "avg_launch_us": round(1e3 * ms / len(rs), 2), "share_of_forward": round(ms / fwd_ms, 3),
+             "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "achieved_gbs": round(by_ / (ms * 1e-3) / 1e9, 1), "bound": bound}
+        e["frac"] = round(e["achieved_tflops"] / peak, 4) if bound == "mfma" else round(e["achieved_gbs"] / PEAK_HBM_GBS, 4)
+        return e
+    other = {"conv3x3_pp_kernel": leg(ppk, "conv3x3_pp_kernel<%s> (ping-pong 3x3, MFMA waves issue their own LDS-DMA behind counted vmcnt)" % a.precision, "mfma"),
+             "conv1x1": leg(k1, "conv1x1_pp_kernel / conv1x1 kernels (all 1x1 convs of the forward)", "hbm")}
     # whole path: algorithmic FLOPs / bytes of one network evaluation (SURVEY 8d accounting: the engine's plan counts 2*MAC of every
     # contraction and in + out activation bytes of every contraction op, weights once) over the measured time per evaluation
     st = eng.stats(B)
@@ -328,6 +356,7 @@ def main():
         "flops_per_launch": dfl / len(dom),
         "algorithmic_bytes_per_launch": dby / len(dom),
         "share_of_forward": round(dms / fwd_ms, 3),
+        "other_kernels": other,
         "all_conv_kernels": {"launches": len(conv), "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2), "share_of_forward": round(cms / fwd_ms, 3)},
         "forward_ms_by_kind": {k: round(v["ms"], 3) for k, v in by.items()},
         "whole_path": {

@@ -161,8 +161,7 @@ __global__ void __launch_bounds__(256) conv3x3_out_kernel(OutArgs p) {
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) abase[kx] = (2 * wave * OP_W + lr + kx) * PXB;
   const int bbase = co * 64 + 16 * (lq ^ ((co >> 1) & 3));
-#pragma unroll 4
-  for (int c = 0; c < nch; ++c) {
+  for (int c = 0; c < nch; ++c) {           // (FIXED: four trips, unrolled by the compiler)
     u32x4 bf[9], af[2][9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
