@@ -313,6 +313,275 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
   }
 }
 
+// ---- persistent form (bf16, T = 256, C = 32 NCH <= 256): one workgroup per CU keeps ITS head's q|k|v weight rows in LDS for every image
+// it visits, so the 96-KB staging, its barrier and its L2 round trips happen once per workgroup instead of once per (image, head), and
+// the next image's x fragments and (a, b) table are in flight while this image's attention runs.  The weights now stay resident, so K / V
+// cannot alias them: the keys go through a 128-key (40-KB) buffer in two rounds - waves 0-3 own keys 0-127 and write them first, every
+// wave attends to them, then waves 4-7 write keys 128-255 (their k / v rows wait in accumulators meanwhile); the online softmax does not
+// care about the key order.  Four barriers per image, none inside a phase.
+// Workgroup b -> (xcd = b & 7, head = (b >> 3) % heads, j = (b >> 3) / heads): image lane = xcd + 8 j, images lane, lane + lanes, ...;
+// the heads of one image run at the same time on the same XCD (x is fetched into that L2 once).
+template <int NCH>
+__global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, int lanes) {
+  using T = bf16;
+  constexpr int V = 8, CHUNK = 32, CH = 64, QB = 2, TT = 256;
+  constexpr int KST = 2, CI = 4, NCT = 12;
+  constexpr int ROW = CH * 2 + 32;
+  constexpr int WBUF = 192 * 64;
+  constexpr int C = NCH * CHUNK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wlds = smem;                                   // [NCH][192 rows][64 B]: resident for the whole kernel
+  char* klds = smem + NCH * WBUF;                      // [128 keys][ROW]
+  char* vlds = klds + 128 * ROW;                       // [128 keys][ROW]
+  float* ablds = reinterpret_cast<float*>(vlds + 128 * ROW);   // [2][a[C] | b[C]]: this image's and the next one's
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.x, kq = b >> 3;
+  const int h = kq % p.heads, ilane = (b & 7) + 8 * (kq / p.heads);
+  if (ilane >= lanes || ilane >= p.N) return;          // whole workgroup, before any barrier
+  const int tok0 = wave * (16 * QB);
+  auto grow = [&](int j) { return p.new_order ? (j >> 6) * C + h * CH + (j & 63) : h * (3 * CH) + j; };
+
+  u32x4 xr[NCH][QB];
+  auto load_x = [&](int n) {
+    const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)n * TT * C;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) xr[c][qb] = *reinterpret_cast<const u32x4*>(xb + (size_t)(tok0 + 16 * qb + lr) * C + c * CHUNK + lq * V);
+  };
+  load_x(ilane);
+  {   // the head's weight rows, once (copied verbatim: see attn_fused_kernel)
+    uint32_t wso[2]; int wdo[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 512 * u, j = min(e >> 2, 191), r = grow(j);
+      wso[u] = ((uint32_t)(r >> 7) * NCH) * 8192u + (uint32_t)(r & 127) * 64u + (e & 3) * 16;
+      wdo[u] = j * 64 + (e & 3) * 16;
+    }
+    const bool second = tid + 512 < 768;
+    const char* wsrc = reinterpret_cast<const char*>(p.w);
+#pragma unroll
+    for (int cl = 0; cl < NCH; cl += 4) {
+      u32x4 t[4][2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t[k][0] = *reinterpret_cast<const u32x4*>(wsrc + wso[0] + (size_t)(cl + k) * 8192);
+        t[k][1] = *reinterpret_cast<const u32x4*>(wsrc + wso[1] + (size_t)(cl + k) * 8192);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        *reinterpret_cast<u32x4*>(wlds + (cl + k) * WBUF + wdo[0]) = t[k][0];
+        if (second) *reinterpret_cast<u32x4*>(wlds + (cl + k) * WBUF + wdo[1]) = t[k][1];
+      }
+    }
+  }
+  if (tid < 2 * C) ablds[tid] = tid < C ? p.ga[(size_t)ilane * C + tid] : p.gb[(size_t)ilane * C + tid - C];
+  float* biaslds = ablds + 4 * C;                      // the head's 192 bias values, row order
+  if (tid < 192) biaslds[tid] = p.bias[grow(tid)];
+  __syncthreads();
+
+  const float c2 = p.scale2 * 1.4426950408889634f;
+  int it = 0;
+  for (int n = ilane; n < p.N; n += lanes, ++it) {
+    const int nn = n + lanes;
+    const bool more = nn < p.N;
+    float abn = 0.f;
+    if (more && tid < 2 * C) abn = tid < C ? p.ga[(size_t)nn * C + tid] : p.gb[(size_t)nn * C + tid - C];
+    const float* ab = ablds + (it & 1) * 2 * C;
+
+    // ---------------- phase 1: q | k | v rows of this head for the wave's tokens; weights resident, x already in registers ----------------
+    f32x4 acc[NCT][QB];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) acc[ct][qb] = *reinterpret_cast<const f32x4*>(biaslds + ct * 16 + 4 * lq);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      u32x4 xf[QB];
+      {
+        float av[V], bv[V];
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + c * CHUNK + lq * V + j);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(ab + C + c * CHUNK + lq * V + j);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { av[j + k] = a4[k]; bv[j + k] = b4[k]; }
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          float f[V];
+          frag_to_float(xr[c][qb], f, T());
+#pragma unroll
+          for (int j = 0; j < V; ++j) f[j] = av[j] * f[j] + bv[j];
+          xf[qb] = float_to_frag(f, T());
+        }
+      }
+      const char* wb = wlds + c * WBUF + lr * 64 + 16 * (lq ^ ((lr >> 1) & 3));
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const u32x4 wf = *reinterpret_cast<const u32x4*>(wb + ct * 1024);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) mma16(acc[ct][qb], wf, xf[qb], T());
+      }
+    }
+    // ---------------- phase 2: q -> B-operand fragments ----------------
+    u32x4 qf[QB][KST];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < KST; ++ks) {
+        bf16x8 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t[r] = (bf16)(acc[2 * ks][qb][r] * c2); t[4 + r] = (bf16)(acc[2 * ks + 1][qb][r] * c2); }
+        qf[qb][ks] = __builtin_bit_cast(u32x4, t);   // q carries ch^-1/2 * log2(e): S^T comes out of the MFMAs in the log2 domain
+      }
+    if (more && tid < 2 * C) ablds[((it + 1) & 1) * 2 * C + tid] = abn;   // read two barriers later at the earliest
+    auto write_kv = [&](int key0) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const int key = key0 + 16 * qb + lr;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const f32x4 kv = acc[4 + ct][qb], vv = acc[8 + ct][qb];
+          bf16x4 kt, vt;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { kt[r] = (bf16)kv[r]; vt[r] = (bf16)vv[r]; }
+          *reinterpret_cast<bf16x4*>(klds + key * ROW + (ct >> 1) * 64 + lq * 16 + (ct & 1) * 8) = kt;
+          *reinterpret_cast<bf16x4*>(vlds + key * ROW + (16 * ct + 4 * lq) * 2) = vt;
+        }
+      }
+    };
+    // ---------------- phase 3: attention over the key buffer, two rounds of 128 keys ----------------
+    f32x4 o[QB][CI];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      m_run[qb] = 0.f; l_run[qb] = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) o[qb][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // The reference offset m_run of a query column enters as the START value of its S^T accumulators, so p = exp2(sacc) with no
+    // multiply-add per element; it moves only when a tile's maximum exceeds it by more than 8 (p <= 2^8), and then the tile is shifted
+    // and O / l rescaled on a wave-uniform slow path.  The very first tile always takes that path (its offset is the tile maximum).
+    // The column maximum is reduced over the four lanes that share a query with two VALU row swaps (v_permlane16_swap /
+    // v_permlane32_swap) instead of two LDS round trips.
+    auto colmax = [&](float v) {
+      const auto s16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, v), __builtin_bit_cast(uint32_t, v), false, false);
+      v = fmaxf(__builtin_bit_cast(float, (uint32_t)s16[0]), __builtin_bit_cast(float, (uint32_t)s16[1]));
+      const auto s32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, v), __builtin_bit_cast(uint32_t, v), false, false);
+      return fmaxf(__builtin_bit_cast(float, (uint32_t)s32[0]), __builtin_bit_cast(float, (uint32_t)s32[1]));
+    };
+    auto attend = [&](bool round0) {
+#pragma unroll 1
+      for (int kt = 0; kt < 2; ++kt) {
+        const char* kb = klds + kt * 64 * ROW;
+        const char* vb = vlds + kt * 64 * ROW;
+        const bool first = round0 && kt == 0;
+        f32x4 sacc[QB][4];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) sacc[qb][mi] = f32x4{-m_run[qb], -m_run[qb], -m_run[qb], -m_run[qb]};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ks = 0; ks < KST; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + (mi * 16 + lr) * ROW + (ks * 4 + lq) * 16);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) mma16(sacc[qb][mi], kf, qf[qb][ks], T());
+          }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          float mx = fmaxf(fmaxf(sacc[qb][0][0], sacc[qb][0][1]), fmaxf(sacc[qb][0][2], sacc[qb][0][3]));
+#pragma unroll
+          for (int mi = 1; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qb][mi][r]);
+          mx = colmax(mx);
+          const float delta = first ? mx : (mx > 8.0f ? mx : 0.0f);
+          if (first || __builtin_amdgcn_ballot_w64(delta != 0.0f) != 0) {   // wave-uniform: some column's offset moves
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+            m_run[qb] += delta;
+            l_run[qb] *= alpha;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sacc[qb][mi][r] -= delta;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[qb][ci][r] *= alpha;
+          }
+          float psum = 0.f;
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float pv = __builtin_amdgcn_exp2f(sacc[qb][mi][r]); sacc[qb][mi][r] = pv; psum += pv; }
+          l_run[qb] += psum;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          u32x4 pfrag[QB];
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            bf16x8 pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pb[r] = (bf16)sacc[qb][2 * s2][r]; pb[4 + r] = (bf16)sacc[qb][2 * s2 + 1][r]; }
+            pfrag[qb] = __builtin_bit_cast(u32x4, pb);
+          }
+          const char* vrow = vb + (32 * s2 + 4 * lq + (lr >> 2)) * ROW + 8 * (lr & 3);
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + ci * 32));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + 16 * ROW + ci * 32));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            const u32x4 vf = u32x4{l2[0], l2[1], h2[0], h2[1]};
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) mma16(o[qb][ci], vf, pfrag[qb], T());
+          }
+        }
+      }
+    };
+    __syncthreads();                       // D: every wave is done with the previous image's second round
+    if (wave < 4) write_kv(tok0);
+    __syncthreads();                       // A: keys 0-127 are in place
+    attend(true);
+    __syncthreads();                       // B: every wave is done with keys 0-127
+    if (wave >= 4) write_kv(tok0 - 128);
+    if (more) load_x(nn);                  // acc is dead in every wave now: the next image's x rides under the second round
+    __syncthreads();                       // C: keys 128-255 are in place
+    attend(false);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float l = l_run[qb];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      T* op = reinterpret_cast<T*>(p.out) + ((size_t)n * TT + tok0 + 16 * qb + lr) * C + h * CH;
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) {
+        bf16x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[qb][ci][r] * inv);
+        *reinterpret_cast<bf16x4*>(op + ci * 16 + 4 * lq) = t;
+      }
+    }
+  }
+}
+
+template <int NCH>
+int launch_fused_pers(const AttnFuseArgs& a, int lanes, hipStream_t s) {
+  auto kern = attn_fused_pers_kernel<NCH>;
+  constexpr size_t lds = (size_t)NCH * 192 * 64 + 2 * 128 * (64 * 2 + 32) + (size_t)4 * NCH * 32 * 4 + 192 * 4;
+  static_assert(lds <= 160 * 1024, "persistent attention block: LDS budget");
+  if (int rc = mi355_allow_big_lds(kern, "attention block (persistent)")) return rc;
+  const int grid = 8 * a.heads * ((lanes + 7) / 8);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, lanes);
+  return 0;
+}
+
 template <typename T, int QB>
 int launch_fused(const AttnFuseArgs& a, hipStream_t s) {
   auto kern = attn_fused_kernel<T, QB>;
@@ -348,7 +617,19 @@ int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream) {
     a.stage_chunks = a.nchunks <= fit ? a.nchunks : fit / 3 * 3;
   }
   int rc;
-  if (d.dtype == 0) rc = d.T == 256 ? launch_fused<float, 2>(a, stream) : launch_fused<float, 1>(a, stream);
+  // persistent form: bf16, 256 tokens, the head's weight rows + a 128-key buffer fit the LDS (C <= 256), and enough (image, head) pairs
+  // that a workgroup visits more than one image (knob attn_fused: bit 1 = off, bits 8.. = image lanes override, tests only)
+  const int knob = (d.knobs ? d.knobs : &mi355_default_debug())->attn_fused;
+  int lanes = 0;
+  if (d.dtype == 1 && d.T == 256 && (d.C == 128 || d.C == 256) && !(knob & 2)) {
+    static const int cus = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return n; }();
+    lanes = std::max(8, cus / d.heads / 8 * 8);
+    if (knob >> 8) lanes = knob >> 8;
+    if (!(knob >> 8) && d.N < 2 * lanes) lanes = 0;   // fewer than two images per workgroup: nothing to amortise
+    if (lanes > d.N) lanes = d.N;
+  }
+  if (lanes > 0) rc = d.C == 256 ? launch_fused_pers<8>(a, lanes, stream) : launch_fused_pers<4>(a, lanes, stream);
+  else if (d.dtype == 0) rc = d.T == 256 ? launch_fused<float, 2>(a, stream) : launch_fused<float, 1>(a, stream);
   else rc = d.T == 256 ? launch_fused<bf16, 2>(a, stream) : launch_fused<bf16, 1>(a, stream);
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());

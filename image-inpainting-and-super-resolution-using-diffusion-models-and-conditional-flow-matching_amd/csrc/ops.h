@@ -119,6 +119,7 @@ struct AttnFusedDesc {
   const void* w = nullptr; const float* bias = nullptr;
   void* out = nullptr;
   int N = 0, T = 0, C = 0, heads = 0, ch = 0, new_order = 0;
+  const mi355_debug_config* knobs = nullptr;
 };
 bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch, const mi355_debug_config* knobs = nullptr);
 int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream);

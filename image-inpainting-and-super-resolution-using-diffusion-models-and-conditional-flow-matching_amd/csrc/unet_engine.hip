@@ -658,7 +658,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     } else if (op.kind == OP_ATTN_FUSED) {
       AttnFusedDesc a; a.dtype = dtype; a.x = TP(op.src0); a.ga = F(l.gna); a.gb = F(l.gnb); a.w = W + op.w_off; a.bias = WF(op.bias_off);
       a.out = TP(op.dst); a.N = B; a.T = s0.H * s0.W; a.C = s0.C; a.heads = op.heads; a.ch = op.ch;
-      a.new_order = net->cfg.use_new_attention_order;
+      a.new_order = net->cfg.use_new_attention_order; a.knobs = &net->knobs;
       rc = attn_fused_launch(a, stream);
       r.kind = MI355_OP_ATTN; r.cin = s0.C; r.cout = s0.C; r.h = s0.H; r.w = s0.W; r.ks = 1;   // ks = 1 marks the fused form
       r.flops = 2.0 * B * (double)a.T * 3.0 * s0.C * s0.C + 4.0 * B * (double)a.T * a.T * s0.C;

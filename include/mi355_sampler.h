@@ -55,7 +55,7 @@ typedef struct mi355_debug_config {
   int32_t gn_apply_max_hw; /* 64: GroupNorm sites on images up to this many pixels write silu(a x + b) themselves (prologue-free conv) */
   int32_t gn_fuse;         /* 1: GroupNorm statistics come from partial sums in the producing convs' epilogues where possible */
   int32_t l2_warm;         /* 1: bit 0: statistics / apply passes touch the next conv's weights; bit 1: finalize passes too */
-  int32_t attn_fused;      /* 1: GroupNorm-apply + qkv + attention in one kernel where the shape allows */
+  int32_t attn_fused;      /* bit 0: GroupNorm-apply + qkv + attention in one kernel where the shape allows; bit 1: never its persistent form; bits 8..: image lanes of the persistent form (tests) */
   int32_t gn_epilogue;     /* 3: bit 0: at the 8x8 / 4x4 levels a GroupNorm (+SiLU) site whose only source is a small-level conv's output is applied in
                             *    that conv's epilogue (no pass); bit 1: at the 16x16 level (a persistent-conv tile = a whole image) the first conv of
                             *    a ResBlock normalises its own output in place (its own template instantiation), the site's finalize launch

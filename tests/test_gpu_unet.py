@@ -465,6 +465,64 @@ def test_engine_error_word_and_diagnostic_switches():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["c256_heads4", "c128_heads2"])
+def test_attention_block_persistent_kernel_matches_per_image_kernel(shape):
+    """AttentionBlock front half (norm -> qkv -> attention, AD/image_diffusion/unet.py:395-401, :433-448) in bf16 mode at 256 tokens:
+    the persistent kernel (one workgroup per CU keeps its head's qkv rows in LDS and walks over images, keys in two rounds of 128)
+    against the one-workgroup-per-(image, head) kernel on the same forward.  The two differ only in where the qkv bias enters the fp32
+    accumulator; both are held to the fp32-mode forward.  The lanes override (debug knob, bits 8..) makes small batches walk several
+    images per workgroup: 2 lanes x 12 images, 5 lanes ragged (5, 5, 5, 5, 4), 8 lanes x 3."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import debug_config
+
+    if shape == "c256_heads4":
+        kw = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(2,),
+                  channel_mult=(1, 2), num_heads=4, num_head_channels=64)
+    else:
+        kw = dict(image_size=16, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(1,),
+                  channel_mult=(1, 2), num_heads=2, num_head_channels=64)
+    B, S = 24, kw["image_size"]
+    x = randn(4300, B, 3, S, S).to(DEV)
+    t = torch.linspace(0, 1, B).to(DEV)
+    sd = None
+
+    def run(precision, **knobs):
+        nonlocal sd
+        net = UNetModel(precision=precision, **kw)
+        if sd is None:
+            sd = synth_state_dict(param_shapes(net), 4301)
+        net.load_state_dict(sd)
+        net.debug = debug_config(**knobs)
+        net.to(DEV)
+        e = net.engine(DEV)
+        y = e.forward(x, t).float().cpu()
+        torch.cuda.synchronize(); e.check()
+        return y
+
+    for spike in (False, True):
+        if spike:   # 3 x the qkv weights = 9 x the logits: peaked softmax rows, the reference offset of the online softmax moves
+            assert any("qkv.weight" in k for k in sd)   # (bf16 rounding of q, k then moves the winners too: both kernels drift from fp32 alike)
+            sd = {k: (v * 3 if "qkv.weight" in k else v) for k, v in sd.items()}
+        _check_attention_block(run, shape + (" spike" if spike else ""), 0.2 if spike else 0.03)
+
+
+def _check_attention_block(run, shape, bound):
+    ref = run("fp32")
+    old = run("bf16", attn_fused=3)            # bit 1: the per-(image, head) kernel
+    err_old = (old - ref).pow(2).mean().sqrt().item()
+    scale = ref.pow(2).mean().sqrt().item()
+    assert err_old < bound * scale, (err_old, scale)
+    for lanes in (2, 5, 8):
+        new = run("bf16", attn_fused=1 | (lanes << 8))
+        assert torch.isfinite(new).all()
+        d = (new - old).pow(2).mean().sqrt().item()
+        err_new = (new - ref).pow(2).mean().sqrt().item()
+        print(f"{shape} lanes {lanes}: new-old {d / scale:.2e}, new-fp32 {err_new / scale:.2e}, old-fp32 {err_old / scale:.2e} (of the output rms)")
+        assert d < 1.5 * err_old, (lanes, d, err_old, scale)        # two bf16 roundings of the same forward: as far apart as each is from fp32
+        assert err_new < 1.15 * err_old + 1e-4 * scale, (lanes, err_new, err_old)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("film", [False, True])
 def test_groupnorm_in_small_conv_epilogue_matches_pass(film):
     """At the 8x8 / 4x4 levels the GroupNorm (+SiLU, +FiLM) site behind a small-level conv is applied in that conv's epilogue (a wave

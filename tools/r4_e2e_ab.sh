@@ -3,7 +3,7 @@
 #   ENVS="name:VAR=val,VAR2=val;name2:..."   TESTS="<pytest files>" (empty = skip)  KEXPR="<pytest -k expression>"
 O=gpurun_out/${TAG:-r4_e2e}; mkdir -p $O
 if [ -n "$TESTS" ]; then
-  if [ -n "$KEXPR" ]; then timeout -k 10 1000 python -m pytest $TESTS -x -q -m gpu -k "$KEXPR" > $O/test.txt 2>&1; else timeout -k 10 1000 python -m pytest $TESTS -x -q -m gpu > $O/test.txt 2>&1; fi; echo "pytest rc=$?" >> $O/test.txt; tail -4 $O/test.txt
+  if [ -n "$KEXPR" ]; then timeout -k 10 1000 python -m pytest $TESTS -x -q -rP -m gpu -k "$KEXPR" > $O/test.txt 2>&1; else timeout -k 10 1000 python -m pytest $TESTS -x -q -m gpu > $O/test.txt 2>&1; fi; echo "pytest rc=$?" >> $O/test.txt; tail -4 $O/test.txt
   grep -q "rc=0" $O/test.txt || exit 1
 fi
 IFS=";" read -ra EV <<< "${ENVS:-pp0:MI355_CONV_PP=0;pp1:MI355_CONV_PP=1}"; unset IFS
