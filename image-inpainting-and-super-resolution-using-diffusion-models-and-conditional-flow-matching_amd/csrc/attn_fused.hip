@@ -321,6 +321,9 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
 // care about the key order.  Four barriers per image, none inside a phase.
 // Workgroup b -> (xcd = b & 7, head = (b >> 3) % heads, j = (b >> 3) / heads): image lane = xcd + 8 j, images lane, lane + lanes, ...;
 // the heads of one image run at the same time on the same XCD (x is fetched into that L2 once).
+#ifndef ATTN_ABLATE
+#define ATTN_ABLATE 0   // experiments only (make variant_src): compile-time ablation mask of the persistent kernel
+#endif
 template <int NCH>
 __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, int lanes) {
   using T = bf16;
@@ -336,22 +339,27 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
   float* ablds = reinterpret_cast<float*>(vlds + 128 * ROW);   // [2][a[C] | b[C]]: this image's and the next one's
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, lq = lane >> 4;
+  const int lr0 = lane & 15, lq0 = lane >> 4;
   const int b = blockIdx.x, kq = b >> 3;
   const int h = kq % p.heads, ilane = (b & 7) + 8 * (kq / p.heads);
   if (ilane >= lanes || ilane >= p.N) return;          // whole workgroup, before any barrier
   const int tok0 = wave * (16 * QB);
+  if constexpr ((ATTN_ABLATE & 512) != 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }   // experiment: the younger wave of each SIMD first
   auto grow = [&](int j) { return p.new_order ? (j >> 6) * C + h * CH + (j & 63) : h * (3 * CH) + j; };
 
   u32x4 xr[NCH][QB];
-  auto load_x = [&](int n) {
+  // quarter j of an image's x fragments (chunks j NCH/4 ...): the next image's quarters are issued one per key tile of the attention
+  // phase - all 16 loads of all 8 waves at once queue up behind the texture addresser (row stride 2C bytes: 16 segments each) and
+  // every wave sat 2-5k cycles in the issue
+  auto load_x = [&](int n, int lr, int lq, auto jc) {
+    constexpr int J = decltype(jc)::value;
     const T* xb = reinterpret_cast<const T*>(p.x) + (size_t)n * TT * C;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+    for (int c = J * (NCH / 4); c < (J + 1) * (NCH / 4); ++c)
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) xr[c][qb] = *reinterpret_cast<const u32x4*>(xb + (size_t)(tok0 + 16 * qb + lr) * C + c * CHUNK + lq * V);
   };
-  load_x(ilane);
+  load_x(ilane, lr0, lq0, IC3<0>()); load_x(ilane, lr0, lq0, IC3<1>()); load_x(ilane, lr0, lq0, IC3<2>()); load_x(ilane, lr0, lq0, IC3<3>());
   {   // the head's weight rows, once (copied verbatim: see attn_fused_kernel)
     uint32_t wso[2]; int wdo[2];
 #pragma unroll
@@ -384,59 +392,117 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
 
   const float c2 = p.scale2 * 1.4426950408889634f;
   int it = 0;
+  // experiments only: cycle stamps of one wave (ATTN_ABLATE & 256), printed at the end
+  constexpr bool STAMP = (ATTN_ABLATE & 256) != 0;
+  unsigned long long ts[16] = {};
+  auto stamp = [&](int i) { if constexpr (STAMP) { if (it == 1) { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } };
   for (int n = ilane; n < p.N; n += lanes, ++it) {
     const int nn = n + lanes;
     const bool more = nn < p.N;
+    // every per-lane LDS / global offset below derives from these two, re-made opaque per image: hoisted out of the loop the two dozen
+    // loop-invariant addresses do not fit the register file next to the fragments and come back as scratch reloads inside phase 1
+    int lr = lr0, lq = lq0;
+    asm volatile("" : "+v"(lr), "+v"(lq));
     float abn = 0.f;
     if (more && tid < 2 * C) abn = tid < C ? p.ga[(size_t)nn * C + tid] : p.gb[(size_t)nn * C + tid - C];
     const float* ab = ablds + (it & 1) * 2 * C;
+    stamp(0);
 
     // ---------------- phase 1: q | k | v rows of this head for the wave's tokens; weights resident, x already in registers ----------------
-    f32x4 acc[NCT][QB];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) acc[ct][qb] = *reinterpret_cast<const f32x4*>(biaslds + ct * 16 + 4 * lq);
+    // (a) GroupNorm affine on all x fragments (the attention norm has no SiLU, unet.py:379,397); (b) three passes over the head's rows -
+    // q, k, v (4 row tiles each) - so only 8 accumulator quads are live and the weight fragments run a whole chunk (4
+    // ds_read_b128) ahead of their MFMAs: the reads of chunk c + 1 are issued between the MFMA pairs of chunk c (explicitly
+    // software-pipelined + sched_group_barrier: left alone, the scheduler keeps two reads in flight and every MFMA pair waits for LDS).
+    u32x4 xf[NCH][QB];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      u32x4 xf[QB];
-      {
-        float av[V], bv[V];
+      float av[V], bv[V];
 #pragma unroll
-        for (int j = 0; j < V; j += 4) {
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + c * CHUNK + lq * V + j);
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(ab + C + c * CHUNK + lq * V + j);
+      for (int j = 0; j < V; j += 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + c * CHUNK + lq * V + j);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(ab + C + c * CHUNK + lq * V + j);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { av[j + k] = a4[k]; bv[j + k] = b4[k]; }
-        }
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-          float f[V];
-          frag_to_float(xr[c][qb], f, T());
-#pragma unroll
-          for (int j = 0; j < V; ++j) f[j] = av[j] * f[j] + bv[j];
-          xf[qb] = float_to_frag(f, T());
-        }
+        for (int k = 0; k < 4; ++k) { av[j + k] = a4[k]; bv[j + k] = b4[k]; }
       }
-      const char* wb = wlds + c * WBUF + lr * 64 + 16 * (lq ^ ((lr >> 1) & 3));
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        const u32x4 wf = *reinterpret_cast<const u32x4*>(wb + ct * 1024);
+      for (int qb = 0; qb < QB; ++qb) {
+        float f[V];
+        frag_to_float(xr[c][qb], f, T());
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) mma16(acc[ct][qb], wf, xf[qb], T());
+        for (int j = 0; j < V; ++j) f[j] = av[j] * f[j] + bv[j];
+        xf[c][qb] = (ATTN_ABLATE & 64) ? xr[c][qb] : float_to_frag(f, T());
       }
     }
-    // ---------------- phase 2: q -> B-operand fragments ----------------
+    stamp(1);
+    const char* wb0 = wlds + lr * 64 + 16 * (lq ^ ((lr >> 1) & 3));
     u32x4 qf[QB][KST];
+    bf16x4 kpk[QB][4], vpk[QB][4];
+    auto rows_pass = [&](auto t0c, auto ntc, auto&& done) {
+      constexpr int T0 = decltype(t0c)::value, NT = decltype(ntc)::value;
+      __builtin_amdgcn_sched_barrier(0);     // the pass is one scheduling region: the groups below count ITS reads and MFMAs only
+      f32x4 acc[NT][QB];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
+      for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-      for (int ks = 0; ks < KST; ++ks) {
-        bf16x8 t;
+        for (int qb = 0; qb < QB; ++qb) acc[ct][qb] = *reinterpret_cast<const f32x4*>(biaslds + (T0 + ct) * 16 + 4 * lq);
+      u32x4 wcur[NT], wnxt[NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { t[r] = (bf16)(acc[2 * ks][qb][r] * c2); t[4 + r] = (bf16)(acc[2 * ks + 1][qb][r] * c2); }
-        qf[qb][ks] = __builtin_bit_cast(u32x4, t);   // q carries ch^-1/2 * log2(e): S^T comes out of the MFMAs in the log2 domain
+      for (int ct = 0; ct < NT; ++ct) wcur[ct] = *reinterpret_cast<const u32x4*>(wb0 + (T0 + ct) * 1024);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);   // bias rows + the first chunk's fragments
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          if (c + 1 < NCH) wnxt[ct] = *reinterpret_cast<const u32x4*>(wb0 + (c + 1) * WBUF + (T0 + ct) * 1024);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) mma16(acc[ct][qb], wcur[ct], xf[c][qb], T());
+        }
+        if (c + 1 < NCH) {
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read ...
+            __builtin_amdgcn_sched_group_barrier(0x008, QB, 0);  // ... then the MFMAs of one row tile
+          }
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) wcur[ct] = wnxt[ct];
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, QB * NT, 0);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      done(acc);
+    };
+    rows_pass(IC3<0>(), IC3<4>(), [&](f32x4 (&acc)[4][QB]) {
+      // q -> B-operand fragments, scaled by ch^-1/2 * log2(e): S^T comes out of the MFMAs in the log2 domain
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+          bf16x8 t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { t[r] = (bf16)(acc[2 * ks][qb][r] * c2); t[4 + r] = (bf16)(acc[2 * ks + 1][qb][r] * c2); }
+          qf[qb][ks] = __builtin_bit_cast(u32x4, t);
+        }
+    });
+    stamp(2);
+    rows_pass(IC3<4>(), IC3<4>(), [&](f32x4 (&acc)[4][QB]) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) kpk[qb][ct][r] = (bf16)acc[ct][qb][r];
+    });
+    stamp(3);
+    rows_pass(IC3<8>(), IC3<4>(), [&](f32x4 (&acc)[4][QB]) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vpk[qb][ct][r] = (bf16)acc[ct][qb][r];
+    });
+    stamp(4);
     if (more && tid < 2 * C) ablds[((it + 1) & 1) * 2 * C + tid] = abn;   // read two barriers later at the earliest
     auto write_kv = [&](int key0) {
 #pragma unroll
@@ -444,12 +510,9 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
         const int key = key0 + 16 * qb + lr;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-          const f32x4 kv = acc[4 + ct][qb], vv = acc[8 + ct][qb];
-          bf16x4 kt, vt;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { kt[r] = (bf16)kv[r]; vt[r] = (bf16)vv[r]; }
-          *reinterpret_cast<bf16x4*>(klds + key * ROW + (ct >> 1) * 64 + lq * 16 + (ct & 1) * 8) = kt;
-          *reinterpret_cast<bf16x4*>(vlds + key * ROW + (16 * ct + 4 * lq) * 2) = vt;
+          // K: the 16-byte slot (ks, lq) holds tile 2 ks (first 8 bytes) and tile 2 ks + 1 (last 8) = the q fragments' channel order
+          *reinterpret_cast<bf16x4*>(klds + key * ROW + (ct >> 1) * 64 + lq * 16 + (ct & 1) * 8) = kpk[qb][ct];
+          *reinterpret_cast<bf16x4*>(vlds + key * ROW + (16 * ct + 4 * lq) * 2) = vpk[qb][ct];   // V: natural [key][channel]
         }
       }
     };
@@ -473,12 +536,14 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
       const auto s32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, v), __builtin_bit_cast(uint32_t, v), false, false);
       return fmaxf(__builtin_bit_cast(float, (uint32_t)s32[0]), __builtin_bit_cast(float, (uint32_t)s32[1]));
     };
-    auto attend = [&](bool round0) {
-#pragma unroll 1
+    auto attend = [&](auto roundc) {
+      constexpr int RND = decltype(roundc)::value;
+#pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         const char* kb = klds + kt * 64 * ROW;
         const char* vb = vlds + kt * 64 * ROW;
-        const bool first = round0 && kt == 0;
+        const bool first = RND == 0 && kt == 0;
+        if (more && !(ATTN_ABLATE & 4)) { if (kt == 0) load_x(nn, lr, lq, IC3<2 * RND>()); else load_x(nn, lr, lq, IC3<2 * RND + 1>()); }   // x fragments are dead since phase 1
         f32x4 sacc[QB][4];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
@@ -488,7 +553,7 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int ks = 0; ks < KST; ++ks) {
-            const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + (mi * 16 + lr) * ROW + (ks * 4 + lq) * 16);
+            const u32x4 kf = (ATTN_ABLATE & 16) ? u32x4{(uint32_t)lane << 8, 0x3c003c00u, (uint32_t)(mi + kt), 0x3c003c00u} : *reinterpret_cast<const u32x4*>(kb + (mi * 16 + lr) * ROW + (ks * 4 + lq) * 16);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) mma16(sacc[qb][mi], kf, qf[qb][ks], T());
           }
@@ -518,7 +583,7 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float pv = __builtin_amdgcn_exp2f(sacc[qb][mi][r]); sacc[qb][mi][r] = pv; psum += pv; }
+            for (int r = 0; r < 4; ++r) { const float pv = (ATTN_ABLATE & 8) ? sacc[qb][mi][r] : __builtin_amdgcn_exp2f(sacc[qb][mi][r]); sacc[qb][mi][r] = pv; psum += pv; }
           l_run[qb] += psum;
         }
 #pragma unroll
@@ -537,22 +602,28 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + ci * 32));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + 16 * ROW + ci * 32));
             const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-            const u32x4 vf = u32x4{l2[0], l2[1], h2[0], h2[1]};
+            const u32x4 vf = (ATTN_ABLATE & 16) ? u32x4{(uint32_t)lane << 8, 0x3c003c00u, (uint32_t)(ci + kt), 0x3c003c00u} : u32x4{l2[0], l2[1], h2[0], h2[1]};
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) mma16(o[qb][ci], vf, pfrag[qb], T());
           }
         }
       }
     };
+    stamp(5);
     __syncthreads();                       // D: every wave is done with the previous image's second round
+    stamp(6);
     if (wave < 4) write_kv(tok0);
     __syncthreads();                       // A: keys 0-127 are in place
-    attend(true);
+    stamp(7);
+    if constexpr (!(ATTN_ABLATE & 1)) attend(IC3<0>());
+    stamp(8);
     __syncthreads();                       // B: every wave is done with keys 0-127
+    stamp(9);
     if (wave >= 4) write_kv(tok0 - 128);
-    if (more) load_x(nn);                  // acc is dead in every wave now: the next image's x rides under the second round
     __syncthreads();                       // C: keys 128-255 are in place
-    attend(false);
+    stamp(10);
+    if constexpr (!(ATTN_ABLATE & 1)) attend(IC3<1>());
+    stamp(11);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float l = l_run[qb];
@@ -568,6 +639,13 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
         *reinterpret_cast<bf16x4*>(op + ci * 16 + 4 * lq) = t;
       }
     }
+    stamp(12);
+  }
+  if constexpr (STAMP) {
+    if (blockIdx.x == 8 && (tid == 0 || tid == 320))
+      printf("[attn stamps] wave %d: affine %llu q %llu k %llu v %llu pack %llu barD %llu kvw+barA %llu att1 %llu barB %llu kvw+barC %llu att2 %llu store %llu | item %llu cycles\n",
+             tid >> 6, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6], ts[8] - ts[7], ts[9] - ts[8],
+             ts[10] - ts[9], ts[11] - ts[10], ts[12] - ts[11], ts[12] - ts[0]);
   }
 }
 
