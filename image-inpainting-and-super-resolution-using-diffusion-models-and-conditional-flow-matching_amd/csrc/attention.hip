@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
   const size_t rowstride = (size_t)3 * p.C;
   const T* base = reinterpret_cast<const T*>(p.qkv) + (size_t)n * p.T * rowstride;
   const int qc = h * p.qoff_h, kc = p.koff + h * p.qoff_h, vc = p.voff + h * p.qoff_h;
+  const float c2 = p.scale2 * 1.4426950408889634f;
 
   // Q^T fragments (B operand): lane holds Q[q0 + 16 qb + lr][ks*CHUNK + lq*V .. +V)
   u32x4 qf[QB][KST];
@@ -67,13 +68,20 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
       const int q = q0 + 16 * qb + lr;
       qf[qb][ks] = u32x4{0u, 0u, 0u, 0u};
       if (q < p.T) qf[qb][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)q * rowstride + qc + ks * CHUNK + lq * V);
+      // q carries ch^-1/2 * log2(e) from here on: S^T comes out of the MFMAs in the log2 domain and the softmax needs no multiply
+      // per element (fp32: exact to rounding; bf16: one more rounding of q, the size of the one the qkv conv's store already made)
+      float f[V];
+      frag_to_float(qf[qb][ks], f, T());
+#pragma unroll
+      for (int j = 0; j < V; ++j) f[j] *= c2;
+      qf[qb][ks] = float_to_frag(f, T());
     }
 
   f32x4 o[QB][CI];
   float m_run[QB], l_run[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+    m_run[qb] = 0.f; l_run[qb] = 0.f;
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci) o[qb][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -106,7 +114,13 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
   };
 
   const int ntiles = (p.T + KT - 1) / KT;
-  const float c2 = p.scale2 * 1.4426950408889634f;
+  // the column maximum over the four lanes that share a query: two VALU row swaps instead of two LDS round trips
+  auto colmax = [&](float v) {
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, v), __builtin_bit_cast(uint32_t, v), false, false);
+    v = fmaxf(__builtin_bit_cast(float, (uint32_t)s16[0]), __builtin_bit_cast(float, (uint32_t)s16[1]));
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, v), __builtin_bit_cast(uint32_t, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)s32[0]), __builtin_bit_cast(float, (uint32_t)s32[1]));
+  };
   load_tile(0);
   store_tile(0);
   for (int kt = 0; kt < ntiles; ++kt) {
@@ -121,7 +135,7 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) sacc[qb][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mi = 0; mi < MT; ++mi) sacc[qb][mi] = f32x4{-m_run[qb], -m_run[qb], -m_run[qb], -m_run[qb]};   // the column's reference offset
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -130,8 +144,10 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) mma16(sacc[qb][mi], kf, qf[qb][ks], T());
       }
-    // ---- online softmax over keys (column = query = lane&15; rows spread over regs and lane>>4), in the log2 domain:
-    //      p = exp2(s * c2 - m2) with c2 = ch^-1/2 * log2(e) folded into one FMA per element (max, fma, exp2, add) ----
+    // ---- online softmax over keys (column = query = lane&15; rows spread over regs and lane>>4), in the log2 domain: the accumulators
+    //      hold s - m_ref, so p = exp2(sacc) (max, exp2, add per element).  The reference offset of a column moves only when a tile's
+    //      maximum exceeds it by more than 8 (p <= 2^8): then the tile is shifted and O / l rescaled on a wave-uniform slow path; the
+    //      first tile always takes it (its offset becomes the tile maximum, whatever its sign) ----
     if ((kt + 1) * KT > p.T) {              // only a ragged last tile has keys to mask (wave-uniform)
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb)
@@ -141,6 +157,7 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
           for (int r = 0; r < 4; ++r)
             if (kt * KT + mi * 16 + lq * 4 + r >= p.T) sacc[qb][mi][r] = -INFINITY;
     }
+    const bool first = kt == 0;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float mx = -INFINITY;
@@ -148,27 +165,31 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qb][mi][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qb], mx * c2);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);  // 0 on the first tile (m_run = -inf)
-      float psum = 0.f;
+      mx = colmax(mx);
+      const float delta = first ? mx : (mx > 8.0f ? mx : 0.0f);
+      if (first || __builtin_amdgcn_ballot_w64(delta != 0.0f) != 0) {
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        m_run[qb] += delta;
+        l_run[qb] *= alpha;
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][mi][r], c2, -m_new));
-          sacc[qb][mi][r] = pv;
-          psum += pv;
-        }
-      l_run[qb] = l_run[qb] * alpha + psum;
-      m_run[qb] = m_new;
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // once the running maxima have settled no query of the wave rescales
+          for (int r = 0; r < 4; ++r) sacc[qb][mi][r] -= delta;
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[qb][ci][r] *= alpha;
       }
+      float psum = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(sacc[qb][mi][r]);
+          sacc[qb][mi][r] = pv;
+          psum += pv;
+        }
+      l_run[qb] += psum;
     }
 
     // ---- O^T += V^T P^T ----
