@@ -328,7 +328,7 @@ template <int NCH>
 __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, int lanes) {
   using T = bf16;
   constexpr int V = 8, CHUNK = 32, CH = 64, QB = 2, TT = 256;
-  constexpr int KST = 2, CI = 4, NCT = 12;
+  constexpr int KST = 2, CI = 4;
   constexpr int ROW = CH * 2 + 32;
   constexpr int WBUF = 192 * 64;
   constexpr int C = NCH * CHUNK;

@@ -35,7 +35,7 @@ void mi355_debug_defaults(mi355_debug_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
   c->conv_ws = 1; c->conv_small = 1; c->conv_min_wgs = 512; c->conv_stagger = 0; c->conv_ablate = 0; c->conv_spin_limit = 1 << 22;
-  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 3; c->conv_pp = 1; c->conv_edge = 1;
+  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 3; c->conv_pp = 1; c->conv_edge = 3;
 }
 int mi355_unet_status(mi355_unet* net, int clear) {
   if (!net) { mi355_set_error("null handle"); return -1; }
@@ -421,6 +421,7 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   const int ctot = cin + cin1, ctot_pad = cpad + cin1;
   ConvDesc d; d.dtype = dtype; d.N = batch; d.Hs = h; d.Ws = w; d.C0 = cpad; d.C1 = cin1; d.ks = ksize; d.Cout = cout;
   d.knobs = &K;
+  if (!x1 && cin <= 8) d.cin_real = cin;   // the padding channels pack_nhwc adds are zero: conv3x3_in_kernel contracts over the first slot only
   const bool pool = resample == 3;   // 2x2 average pool of the (normalised) input: a pre-pass, then a plain conv
   MI355_REQUIRE(!(pool && x1), -4, "conv2d: pooling over a channel concat is not supported");
   if (pool) { d.Hs = h / 2; d.Ws = w / 2; }

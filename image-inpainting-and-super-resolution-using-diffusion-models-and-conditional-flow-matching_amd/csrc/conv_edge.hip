@@ -191,6 +191,122 @@ __global__ void __launch_bounds__(256) conv3x3_out_kernel(OutArgs p) {
   }
 }
 
+
+// ---- the network's FIRST conv (unet.py:575: conv_nd(dims, in_channels, model_channels, 3, padding=1)): K = 9 taps x 3 ... 8 real channels.
+// The input tensor is NHWC with its channels padded to one 64-byte chunk (pack_nhwc); only the first 16-byte slot of a pixel holds real
+// channels (cin_real <= 8) and the packed weights of the other slots are zero, so the contraction runs over (tap, 8 channels): 72 -> 96
+// = three 32-deep MFMA steps of four taps each (taps 9-11 are zero rows) instead of nine steps that are 90 % padding.  One workgroup =
+// one 16x16 pixel tile x 128 output channels, 4 waves x 4 tile rows; what is left is the 256-byte-per-pixel output stream (16-byte
+// stores via v_permlane16_swap) and the GroupNorm partial sums of the output (common.h GnPartial; slot = one wave's 64 pixels).
+struct InArgs {
+  const void* src; const void* w; const float* bias; void* out;
+  float* gn_stats; int gn_slots;
+  int N, H, W, tiles_x, tiles_y;
+};
+
+template <bool GN>
+__global__ void __launch_bounds__(256, 4) conv3x3_in_kernel(InArgs p) {
+  constexpr int NT = 8;                       // 16-channel tiles of the 128 output channels
+  constexpr int PW = 18, NPX = PW * PW;       // haloed patch
+  __shared__ __attribute__((aligned(16))) char wl[12 * 128 * 16];       // [tap (9 real + 3 zero)][row][channels 0-7]
+  __shared__ __attribute__((aligned(16))) char xl[(NPX + 1) * 16];      // [patch pixel][channels 0-7] + one zero slot
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr0 = lane & 15, lq0 = lane >> 4;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int n = blockIdx.x / tpi, trem = blockIdx.x - n * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+
+  // weights: slot 0 of every (tap, row) of the packed image ([tap][128 rows][64 B], slots swizzled by (row >> 1) & 3)
+  for (int e = tid; e < 12 * 128; e += 256) {
+    const int tap = e >> 7, row = e & 127;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (tap < 9) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.w) + (size_t)tap * 8192 + row * 64 + 16 * ((row >> 1) & 3));
+    *reinterpret_cast<u32x4*>(wl + e * 16) = v;
+  }
+  // patch: slot 0 of every pixel of the haloed tile (zero outside the image)
+  for (int q = tid; q < NPX + 1; q += 256) {
+    const int py = q / PW, px = q - py * PW;
+    const int gy = ty * 16 + py - 1, gx = tx * 16 + px - 1;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (q < NPX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+      v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.src) + (((size_t)n * p.H + gy) * p.W + gx) * 64);
+    *reinterpret_cast<u32x4*>(xl + q * 16) = v;
+  }
+  __syncthreads();
+
+  float gs[NT], gq[NT];     // GroupNorm partial sums of this wave's 64 pixels, per channel tile (GnPartial's layout, 16 registers instead of 32)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { gs[nt] = 0.f; gq[nt] = 0.f; }
+  constexpr bool do_gn = GN;   // (a run-time flag costs a branch and a phi per store group)
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    const int r0 = wave * 4 + half * 2;                 // two tile rows at a time: 64 accumulator registers, four workgroups per CU
+    // lane ids re-made opaque per half: hoisted out of this loop, the 24 weight fragments (96 registers) and a dozen offsets would
+    // halve the occupancy or come back as scratch reloads whose vmcnt waits also wait for the previous half's stores
+    int lr = lr0, lq = lq0;
+    asm volatile("" : "+v"(lr), "+v"(lq));
+    const int wofs = (lq * 128 + lr) * 16;
+    const int co_s = (lq & 1) * 16 + (lq >> 1) * 8;     // channel of this lane's 16-byte store within a pair of channel tiles
+    // lane (lr, lq) of k-step ks holds tap 4 ks + lq: weights of row nt * 16 + lr (A operand), pixel (r + ky, lr + kx) (B operand)
+    int boff[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int tap = 4 * ks + lq, ky = tap / 3, kx = tap - 3 * ky;
+      boff[ks] = tap < 9 ? (ky * PW + lr + kx) * 16 : NPX * 16;
+    }
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nt * 16 + 4 * lq);
+      acc[0][nt] = b4; acc[1][nt] = b4;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      u32x4 bf[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) bf[mi] = *reinterpret_cast<const u32x4*>(xl + boff[ks] + (boff[ks] == NPX * 16 ? 0 : (r0 + mi) * PW * 16));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(wl + wofs + (4 * ks * 128 + nt * 16) * 16);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) mma16(acc[mi][nt], af, bf[mi], bf16());
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int gy = ty * 16 + r0 + mi, gx = tx * 16 + lr;
+      char* op = reinterpret_cast<char*>(p.out) + ((((size_t)n * p.H + gy) * p.W + gx) * 128 + co_s) * 2;
+#pragma unroll
+      for (int k = 0; k < NT / 2; ++k) {
+        const f32x4 va = acc[mi][2 * k], vb = acc[mi][2 * k + 1];
+        if constexpr (do_gn) {
+          gs[2 * k] += (va[0] + va[1]) + (va[2] + va[3]);
+          gq[2 * k] = __builtin_fmaf(va[0], va[0], __builtin_fmaf(va[1], va[1], __builtin_fmaf(va[2], va[2], __builtin_fmaf(va[3], va[3], gq[2 * k]))));
+          gs[2 * k + 1] += (vb[0] + vb[1]) + (vb[2] + vb[3]);
+          gq[2 * k + 1] = __builtin_fmaf(vb[0], vb[0], __builtin_fmaf(vb[1], vb[1], __builtin_fmaf(vb[2], vb[2], __builtin_fmaf(vb[3], vb[3], gq[2 * k + 1]))));
+        }
+        bf16x4 ta, tb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ta[q] = (bf16)va[q]; tb[q] = (bf16)vb[q]; }
+        const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+        const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
+        const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
+        *reinterpret_cast<u32x4*>(op + k * 64) = u32x4{w0[0], w1[0], w0[1], w1[1]};
+      }
+    }
+  }
+  if constexpr (do_gn) {   // slot = (tile of the image, wave): this wave's 64 pixels x all 128 channels
+    const int slot = trem * 4 + wave;
+    // lane (lq, lr = nt) stores the pair of quad 4 nt + lq (GnPartial::store): 16-lane DPP row sums over the pixels
+    float ms = 0.f, mq = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float ts = GnPartial<1>::row_sum(gs[nt]), tq = GnPartial<1>::row_sum(gq[nt]);
+      if (lr0 == nt) { ms = ts; mq = tq; }
+    }
+    if (lr0 < NT) *reinterpret_cast<f32x2*>(p.gn_stats + (((size_t)n * p.gn_slots + slot) * (size_t)(128 >> 2) + (lr0 * 4 + lq0)) * 2) = f32x2{ms, mq};
+  }
+}
+
 }  // namespace
 
 // 0 = launched, 1 = not eligible (the caller goes on to the generic kernel), < 0 = error.  Switch: mi355_debug_config::conv_edge.
@@ -222,5 +338,25 @@ int conv_out_try_launch(const ConvDesc& d, hipStream_t stream) {
   else rc = fixed ? go(conv3x3_out_kernel<bf16, true>) : go(conv3x3_out_kernel<bf16, false>);
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// The first conv (see conv3x3_in_kernel).  0 = launched, 1 = not eligible, < 0 = error.  Switch: mi355_debug_config::conv_edge bit 1.
+int conv_in_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
+  const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
+  if (!(K.conv_edge & 2)) return 1;
+  if (d.dtype != 1 || d.ks != 3 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.src1 || d.res || d.emb || d.pro_a || d.act_out) return 1;
+  if (d.cin_real < 1 || d.cin_real > 8 || d.C0 != 32 || d.Cout != 128 || conv_tile_n(d.Cout) != 128) return 1;
+  if (d.Hs % 16 != 0 || d.Ws % 16 != 0) return 1;
+  InArgs a;
+  a.src = d.src0; a.w = d.w; a.bias = d.bias; a.out = d.out;
+  a.N = d.N; a.H = d.Hs; a.W = d.Ws; a.tiles_x = d.Ws / 16; a.tiles_y = d.Hs / 16;
+  const int slots = a.tiles_x * a.tiles_y * 4;
+  a.gn_stats = nullptr; a.gn_slots = 0;
+  if (d.gn_stats && slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = slots; }
+  if (a.gn_stats) hipLaunchKernelGGL(conv3x3_in_kernel<true>, dim3(d.N * a.tiles_x * a.tiles_y), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(conv3x3_in_kernel<false>, dim3(d.N * a.tiles_x * a.tiles_y), dim3(256), 0, stream, a);
+  MI355_CHECK_HIP(hipGetLastError());
+  if (gn_slots_used) *gn_slots_used = a.gn_slots;
   return 0;
 }

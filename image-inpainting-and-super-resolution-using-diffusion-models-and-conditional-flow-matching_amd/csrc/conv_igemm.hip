@@ -737,6 +737,10 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
     const int r = conv_out_try_launch(d, stream);
     if (r <= 0) return r;
   }
+  {
+    const int r = conv_in_try_launch(d, stream, gn_slots_used);
+    if (r <= 0) return r;
+  }
   const int CH = chunk_of(d.dtype);
   const int Cin = d.C0 + d.C1;
   MI355_REQUIRE(d.ks == 1 || d.ks == 3, -1, "conv: kernel size must be 1 or 3");

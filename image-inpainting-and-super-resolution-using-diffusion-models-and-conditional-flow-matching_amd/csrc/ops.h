@@ -44,6 +44,7 @@ struct ConvDesc {
   void* act_out = nullptr; const float* act_gamma = nullptr; const float* act_beta = nullptr;
   const float* act_film = nullptr; int act_film_stride = 0; float act_eps = 1e-5f; int act_silu = 0, act_raw = 1;
   const void* warm = nullptr; uint32_t warm_bytes = 0;
+  int cin_real = 0;                         // > 0: only the first cin_real channels of src0 are non-zero (the network's first conv: in_channels padded to a chunk)
 };
 
 struct ConvGeom {
@@ -62,6 +63,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = null
 int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
 // 1x1 GEMM in the ping-pong structure (conv_pp1.inc.h: 256 pixels x 256 channels, both operands streamed by DMA): same return convention
 int conv1x1_pp_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
+int conv_in_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);   // conv_edge.hip: the network's first conv
 // the network's last conv (GN + SiLU prologue, <= 4 output channels, NCHW fp32) as a streaming kernel (conv_edge.hip): same convention
 int conv_out_try_launch(const ConvDesc& d, hipStream_t stream);
 

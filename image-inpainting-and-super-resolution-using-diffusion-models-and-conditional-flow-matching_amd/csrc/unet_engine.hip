@@ -601,6 +601,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
         c.pro_a = sp; c.pro_b = sp + (size_t)B * net->site_C[op.gn_site];
       }
       c.w = W + op.w_off; c.bias = WF(op.bias_off); c.Cout = op.Cout;
+      if (op.src0 == net->in_tensor) c.cin_real = net->cfg.in_channels;
       if (op.emb_off >= 0) { c.emb = embp + op.emb_off; c.emb_stride = estride; }
       if (op.res >= 0) { c.res = TP(op.res); c.res_mode = op.res_mode; }
       c.out_mode = op.out_mode;

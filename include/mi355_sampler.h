@@ -63,8 +63,9 @@ typedef struct mi355_debug_config {
   int32_t conv_pp;         /* 1: prologue-free 3x3 convs with Cout % 256 == 0 on images >= 16x16 run on the ping-pong kernel (conv_pp.inc.h: 8 MFMA
                             *    waves in two groups that alternate LDS-read / DMA segments with MFMA segments) when the launch has at least one
                             *    256-pixel x 256-channel tile per CU; 2: whenever the shape is eligible (tests); 0: never */
-  int32_t conv_edge;       /* 1: bit 0: the network's last conv (GroupNorm + SiLU -> 3x3 -> <= 4 channels, NCHW fp32) runs on the streaming kernel of
-                            *    conv_edge.hip instead of the generic MFMA tile kernel */
+  int32_t conv_edge;       /* bit 0: the network's last conv (GroupNorm + SiLU -> 3x3 -> <= 4 channels, NCHW fp32) runs on the streaming kernel of
+                            *    conv_edge.hip instead of the generic MFMA tile kernel; bit 1: the first conv (<= 8 real input channels -> 128,
+                            *    bf16) on conv3x3_in_kernel of the same file (contraction over tap x 8 channels instead of tap x padded chunk) */
   int32_t reserved[2];
 } mi355_debug_config;
 void mi355_debug_defaults(mi355_debug_config* out);

@@ -123,6 +123,20 @@ def test_out_conv_streaming_kernel(ops, dtype, rtol, atol):
         torch.testing.assert_close(got, old, rtol=rtol, atol=atol)
 
 
+def test_first_conv_kernel(ops):
+    """UNetModel.input_blocks[0] = conv3x3(in_channels -> model_channels) (unet.py:575) in bf16 mode on conv3x3_in_kernel (conv_edge bit 1:
+    contraction over tap x the 8 channels of a pixel's first 16-byte slot) against torch and against the generic tile kernel on the same
+    inputs: 3 / 6 / 1 / 8 input channels (x alone, x || condition, MNIST, a full slot), one tile, many tiles, 128-pixel images."""
+    for (B, Ci, H, W) in [(5, 3, 32, 32), (3, 6, 32, 32), (2, 1, 16, 16), (2, 8, 48, 16), (2, 6, 128, 128), (70, 3, 64, 64)]:
+        x = randn(700 + Ci + H, B, Ci, H, W) * 1.3
+        sd = synth_state_dict({"weight": (128, Ci, 3, 3), "bias": (128,)}, 710 + Ci)
+        ref = F.conv2d(x, sd["weight"], sd["bias"], padding=1)
+        got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], dtype=_lib.MI355_BF16, debug=_lib.debug_config(conv_edge=3)).cpu()
+        old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], dtype=_lib.MI355_BF16, debug=_lib.debug_config(conv_edge=1)).cpu()
+        torch.testing.assert_close(got, ref, rtol=3e-2, atol=3e-2)
+        torch.testing.assert_close(got, old, rtol=1e-2, atol=1e-2)   # same bf16 operands, same bf16 output rounding: only the fp32 summation order differs
+
+
 @pytest.mark.parametrize("dtype,tol", [(_lib.MI355_F32, 2e-5), (_lib.MI355_BF16, 2e-2)])
 def test_qkv_attention(ops, golden, dtype, tol):
     g = golden("attention")

@@ -465,6 +465,37 @@ def test_engine_error_word_and_diagnostic_switches():
 
 
 @pytest.mark.gpu
+def test_first_conv_kernel_in_network_feeds_groupnorm_partial_sums():
+    """bf16 forward with the first conv on conv3x3_in_kernel (conv_edge bit 1) and on the generic kernel: the new kernel also leaves the
+    GroupNorm partial sums the first ResBlock's norm is finalised from (64-pixel slots), so the whole forward has to agree, with and
+    without a condition (in_channels 3 / 6)."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import debug_config
+
+    for cin in (3, 6):
+        kw = dict(image_size=32, in_channels=cin, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(),
+                  channel_mult=(1, 2), num_heads=4, num_head_channels=64)
+        B = 72
+        x = randn(4400 + cin, B, cin, 32, 32).to(DEV)
+        t = torch.linspace(0, 1, B).to(DEV)
+        sd = None
+        outs = {}
+        for edge in (1, 3):
+            net = UNetModel(precision="bf16", **kw)
+            if sd is None:
+                sd = synth_state_dict(param_shapes(net), 4401)
+            net.load_state_dict(sd)
+            net.debug = debug_config(conv_edge=edge)
+            net.to(DEV)
+            e = net.engine(DEV)
+            outs[edge] = e.forward(x, t).float().cpu()
+            torch.cuda.synchronize(); e.check()
+        scale = outs[1].pow(2).mean().sqrt().item()
+        d = (outs[3] - outs[1]).pow(2).mean().sqrt().item()
+        assert d < 1.5e-2 * scale, (cin, d, scale)   # two bf16 roundings of one forward (fp32-vs-bf16 is ~9e-3 of the rms); wrong statistics would be O(1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["c256_heads4", "c128_heads2"])
 def test_attention_block_persistent_kernel_matches_per_image_kernel(shape):
     """AttentionBlock front half (norm -> qkv -> attention, AD/image_diffusion/unet.py:395-401, :433-448) in bf16 mode at 256 tokens:
