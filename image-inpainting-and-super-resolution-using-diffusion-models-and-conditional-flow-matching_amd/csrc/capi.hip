@@ -30,7 +30,7 @@ const mi355_debug_config& mi355_default_debug() {
 
 extern "C" {
 
-int mi355_version(void) { return 101; }
+int mi355_version(void) { return 102; }
 void mi355_debug_defaults(mi355_debug_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));

@@ -36,6 +36,11 @@ extern "C" {
 #define MI355_F32 0  /* fp32 storage, exact f32 MFMA (v_mfma_f32_16x16x4_f32): tight-parity mode   */
 #define MI355_BF16 1 /* bf16 storage + bf16 MFMA, fp32 accumulate; GN stats / softmax / x state fp32 */
 
+/* ABI version = 100 * major + minor.  The minor number counts additive changes; 102 (round 4): mi355_debug_config gained conv_pp and
+ * conv_edge (carved out of its reserved tail: the struct's size is unchanged), attn_fused became a bit mask, mi355_unet_read_tensor
+ * returns MI355_ERR_UNSUPPORTED for a tensor the plan did not materialise as stored.  Callers that fill a mi355_debug_config must start
+ * from mi355_debug_defaults() (or zero the struct and set every field): a field this header does not know yet is then at its shipped
+ * value, and the reserved words must stay 0. */
 int mi355_version(void);
 const char* mi355_last_error(void);
 

@@ -12,7 +12,7 @@ import re
 import sqlite3
 import sys
 
-NAMES = (r"(attn_fused_kernel|conv3x3_ws_kernel|conv_igemm_kernel|conv1x1_kernel|gn_affine_kernel|gn_finalize_kernel|attention_kernel|"
+NAMES = (r"(attn_fused_pers_kernel|attn_fused_kernel|conv3x3_ws_kernel|conv3x3_pp_kernel|conv1x1_pp_kernel|conv3x3_small_kernel|conv3x3_out_kernel|conv3x3_in_kernel|conv_igemm_kernel|conv1x1_kernel|gn_affine_kernel|gn_finalize_kernel|attention_kernel|"
          r"affine_pool_kernel|linear_small_kernel|linear_kernel|timestep_embedding_kernel|pack_nhwc_kernel|unpack_nchw_kernel|"
          r"resample\w*_kernel|ew4\w*|rk_\w+_kernel)")
 

@@ -36,9 +36,12 @@ def per_kernel(db_path, counter):
 
 
 def short(name):
-    name = re.sub(r"\(.*", "", name)
-    m = re.search(r"(attn_fused_kernel|attention_bwd_\w+_kernel|conv3x3_ws_kernel|conv_igemm_kernel|conv1x1_kernel|gn_affine_kernel|gn_finalize_kernel|attention_kernel|affine_pool_kernel|"
-                  r"linear_small_kernel|linear_kernel|timestep_embedding_kernel|pack_nhwc_kernel|unpack_nchw_kernel|resample\w*_kernel|ew4\w*|rk_\w+_kernel)", name)
+    """base kernel name of a mangled or demangled symbol (instantiations of one template are summed)"""
+    name = name.replace("(anonymous namespace)::", "")
+    m = re.search(r"_ZN12_GLOBAL__N_1\d+([A-Za-z_]\w*?_kernel)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"([A-Za-z_]\w*_kernel|ew4\w*|__amd_rocclr_\w+)", re.sub(r"^void\s+", "", name))
     return m.group(1) if m else name[:60]
 
 
