@@ -341,7 +341,9 @@ def main():
         e["frac"] = round(e["achieved_tflops"] / peak, 4) if bound == "mfma" else round(e["achieved_gbs"] / PEAK_HBM_GBS, 4)
         return e
     other = {"conv3x3_pp_kernel": leg(ppk, "conv3x3_pp_kernel<%s> (ping-pong 3x3, MFMA waves issue their own LDS-DMA behind counted vmcnt)" % a.precision, "mfma"),
-             "conv1x1": leg(k1, "conv1x1_pp_kernel / conv1x1 kernels (all 1x1 convs of the forward)", "hbm")}
+             "conv1x1": leg(k1, "conv1x1_pp_kernel / conv1x1 kernels (all 1x1 convs of the forward)", "hbm"),
+             "attention_block": leg([r for r in recs if r["kind"] == "attention" and r["ks"] == 1],
+                                    "attn_fused_pers_kernel / attn_fused_kernel (GroupNorm-apply + qkv + attention in one launch)", "mfma")}
     # whole path: algorithmic FLOPs / bytes of one network evaluation (SURVEY 8d accounting: the engine's plan counts 2*MAC of every
     # contraction and in + out activation bytes of every contraction op, weights once) over the measured time per evaluation
     st = eng.stats(B)

@@ -7,6 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r4_final
 mkdir -p $O
 cd $R
+rm -f $O/bench_lines_all_workloads.jsonl $O/bench_log.txt
 run() { echo "== $*" >> $O/bench_log.txt; python bench.py "$@" 2>>$O/bench_log.txt | tee -a $O/bench_lines_all_workloads.jsonl | cut -c1-160; }
 run --steps 10 --warmup 3 --profile-out $O/per_op_cifar_b256.json || exit 1
 run --steps 2 --warmup 1 --precision fp32 --no-cpu-baseline || exit 1
@@ -19,7 +20,9 @@ run --steps 2 --warmup 1 --workload px128_inpaint_ddim100_b128 --profile-out $O/
 echo "bench lines done" 
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 1 --warmup 1 --nfe 4 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $CMD > $O/stats.log 2>&1 || exit 1
+# kernel stats: the bench command at its full length (100 network evaluations) - a 8-evaluation run is over before the clocks have
+# settled, and its averages read ~9 % above the live HIP-event figure of the bench line
+rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $O/sq1 -o s -- $CMD > $O/sq1.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_WAVES -d $O/sq2 -o s -- $CMD > $O/sq2.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f -- $CMD > $O/fetch.log 2>&1 || exit 1
