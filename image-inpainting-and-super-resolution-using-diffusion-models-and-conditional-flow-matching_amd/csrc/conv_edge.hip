@@ -346,7 +346,7 @@ int conv_in_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used
   const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
   if (!(K.conv_edge & 2)) return 1;
   if (d.dtype != 1 || d.ks != 3 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.src1 || d.res || d.emb || d.pro_a || d.act_out) return 1;
-  if (d.cin_real < 1 || d.cin_real > 8 || d.C0 != 32 || d.Cout != 128 || conv_tile_n(d.Cout) != 128) return 1;
+  if (d.cin_real < 1 || d.cin_real > 8 || d.C0 != 32 || d.Cout != 128 || conv_tile_n(d.Cout) != 128 || !d.bias) return 1;
   if (d.Hs % 16 != 0 || d.Ws % 16 != 0) return 1;
   InArgs a;
   a.src = d.src0; a.w = d.w; a.bias = d.bias; a.out = d.out;
