@@ -76,6 +76,10 @@ typedef struct mi355_debug_config {
 void mi355_debug_defaults(mi355_debug_config* out);
 
 /* ---- U-Net (AD/image_diffusion/unet.py:490-728 UNetModel; == torchcfm UNetModelWrapper) ---------- */
+/* ZERO-INITIALISE this struct (`mi355_unet_config cfg = {0};`, `memset`) before filling it: fields are only ever added at its end, a zero
+ * field means "the behaviour before the field existed" (debug = NULL: shipped kernel paths), and mi355_unet_create dereferences `debug`
+ * when it is not NULL - a caller compiled against an older header that leaves the tail uninitialised hands it a garbage pointer.
+ * Compare mi355_version() / 100 with the major version the caller was built for before the first call. */
 
 typedef struct mi355_unet_config {
   int32_t image_size;
