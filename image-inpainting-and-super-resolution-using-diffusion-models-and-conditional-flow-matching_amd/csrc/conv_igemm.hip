@@ -714,10 +714,13 @@ ConvGeom conv_geometry(const ConvDesc& d) {
   r.grid_m = g.groups * g.tiles_x * g.tiles_y; r.grid_n = (d.Cout + g.BN - 1) / g.BN;
   const int CH = d.dtype == 0 ? 16 : 32;
   const mi355_debug_config& Kg = d.knobs ? *d.knobs : mi355_default_debug();
-  if (d.C0 % CH == 0 && d.C1 % CH == 0 &&
-      pp_eligible(Kg.conv_pp, d.ks, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.pro_a != nullptr, d.N, g.Ho, g.Wo, d.Cout)) {
-    r.BM = 256; r.BN = 256; r.lds_bytes = pp::LDS_BYTES;   // ping-pong kernel (conv_pp.inc.h)
-    return r;
+  if (d.C0 % CH == 0 && d.C1 % CH == 0) {
+    const int pc = pp_config(Kg.conv_pp, d.ks, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.pro_a != nullptr, d.pro_silu != 0, d.N, g.Ho, g.Wo, d.Cout);
+    if (pc >= 0) {   // ping-pong kernel (conv_pp.inc.h): 256 px x 256 ch or 512 px x 128 ch tiles
+      r.BM = pc == 0 ? 256 : 512; r.BN = pc == 0 ? 256 : 128;
+      r.lds_bytes = pc == 0 ? pp::D<0>::lds_bytes(d.pro_a != nullptr) : pp::D<1>::lds_bytes(d.pro_a != nullptr);
+      return r;
+    }
   }
   if (d.C0 % CH == 0 && d.C1 % CH == 0 &&
       ws_eligible((d.knobs ? d.knobs : &mi355_default_debug())->conv_ws, d.ks, g.BM, g.BN, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.N, g.Ho, g.Wo, d.Cout)) {
@@ -780,12 +783,24 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
   dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
   const bool gn_ok = d.gn_stats && d.out_mode == OUT_NHWC && g.G == 1 && d.Cout % g.BN == 0 && d.Cout % 4 == 0;
-  {   // prologue-free inputs, 256-channel output tiles: ping-pong kernel (conv_pp.inc.h); same statistics slots as the warp-specialised kernel
-    const int pp_slots = 2 * ((g.Wo + pp::VW - 1) / pp::VW) * ((g.Ho + pp::TH - 1) / pp::TH);
-    if (gn_ok && pp_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = pp_slots; }
-    const int r = d.dtype == 0 ? launch_pp<float>(a, K.conv_pp, d.ks, stream) : launch_pp<bf16>(a, K.conv_pp, d.ks, stream);
-    if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); if (gn_slots_used) *gn_slots_used = a.gn_slots; return 0; }
+  {   // ping-pong kernel (conv_pp.inc.h): 256- or 128-channel output tiles, input as it is or through the in-LDS GroupNorm + SiLU prologue
+    const int pc = pp_config(K.conv_pp, d.ks, g.G, g.bn_pack, d.out_mode, g.stride, a.nchunks, d.pro_a != nullptr, d.pro_silu != 0, d.N, g.Ho, g.Wo, d.Cout);
+    const int pp_slots = pc >= 0 ? pp_gn_slots(pc, g.Ho, g.Wo) : 0;
+    if (pc >= 0 && gn_ok && pp_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = pp_slots; }
+    int pp_act = 0;
+    if (d.act_out && act_done && (K.gn_epilogue & 2) && d.act_out == d.out && !d.act_raw) {   // in place: the activated tensor replaces the raw one
+      a.act_out = d.act_out; a.act_gamma = d.act_gamma; a.act_beta = d.act_beta; a.act_film = d.act_film; a.act_film_stride = d.act_film_stride;
+      a.act_eps = d.act_eps; a.act_silu = d.act_silu; a.act_raw = 0;
+    }
+    const int r = d.dtype == 0 ? launch_pp<float>(a, K.conv_pp, d.ks, stream, &pp_act) : launch_pp<bf16>(a, K.conv_pp, d.ks, stream, &pp_act);
+    if (r == 0) {
+      MI355_CHECK_HIP(hipGetLastError());
+      if (pp_act) { if (act_done) *act_done = 1; if (gn_slots_used) *gn_slots_used = 0; }
+      else if (gn_slots_used) *gn_slots_used = a.gn_slots;
+      return 0;
+    }
     if (r < 0) return r;
+    a.act_out = nullptr;
     a.gn_stats = nullptr; a.gn_slots = 0;
   }
   {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)

@@ -308,7 +308,7 @@ static int pp1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_u
   if (nchunks < 8 || (nchunks & 3) || (HW % BM) != 0) return 1;
   if (d.res && d.res_mode != RES_SAME) return 1;
   const int n_mt = (int)((long)d.N * HW / BM), n_nt = d.Cout / BN;
-  if (K.conv_pp < 2 && n_mt * n_nt < ws_num_cus()) return 1;
+  if ((K.conv_pp & 3) < 2 && n_mt * n_nt < ws_num_cus()) return 1;
   ConvKArgs a{};
   a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = nchunks;
   a.N = d.N; a.Hs = d.Hs; a.Ws = d.Ws; a.Hc = d.Hs; a.Wc = d.Ws; a.Ho = d.Hs; a.Wo = d.Ws;

@@ -36,7 +36,8 @@ extern "C" {
 #define MI355_F32 0  /* fp32 storage, exact f32 MFMA (v_mfma_f32_16x16x4_f32): tight-parity mode   */
 #define MI355_BF16 1 /* bf16 storage + bf16 MFMA, fp32 accumulate; GN stats / softmax / x state fp32 */
 
-/* ABI version = 100 * major + minor.  The minor number counts additive changes; 102 (round 4): mi355_debug_config gained conv_pp and
+/* ABI version = 100 * major + minor.  The minor number counts additive changes; 103 (round 5): conv_pp became a bit mask (bits 2, 3: the
+ * prologue and narrow forms of the ping-pong kernel).  102 (round 4): mi355_debug_config gained conv_pp and
  * conv_edge (carved out of its reserved tail: the struct's size is unchanged), attn_fused became a bit mask, mi355_unet_read_tensor
  * returns MI355_ERR_UNSUPPORTED for a tensor the plan did not materialise as stored.  Callers that fill a mi355_debug_config must start
  * from mi355_debug_defaults() (or zero the struct and set every field): a field this header does not know yet is then at its shipped
@@ -65,9 +66,11 @@ typedef struct mi355_debug_config {
                             *    that conv's epilogue (no pass); bit 1: at the 16x16 level (a persistent-conv tile = a whole image) the first conv of
                             *    a ResBlock normalises its own output in place (its own template instantiation), the site's finalize launch
                             *    disappears and the second conv runs prologue-free; 0: gn_affine pass / finalize launch + prologue */
-  int32_t conv_pp;         /* 1: prologue-free 3x3 convs with Cout % 256 == 0 on images >= 16x16 run on the ping-pong kernel (conv_pp.inc.h: 8 MFMA
-                            *    waves in two groups that alternate LDS-read / DMA segments with MFMA segments) when the launch has at least one
-                            *    256-pixel x 256-channel tile per CU; 2: whenever the shape is eligible (tests); 0: never */
+  int32_t conv_pp;         /* 13: the ping-pong 3x3 kernel (conv_pp.inc.h: 8 MFMA waves in two groups that alternate LDS-read / DMA segments with MFMA
+                            *    segments).  Bits 0-1: 1 = it takes an eligible conv when the launch has at least one tile per CU, 2 = whenever the
+                            *    shape is eligible (tests), 0 = never.  Bit 2 (4): convs with a GroupNorm + SiLU input prologue too (applied in LDS, in
+                            *    place; otherwise such convs stay on the warp-specialised kernel).  Bit 3 (8): the narrow geometry (512 pixels x 128
+                            *    channels) for Cout % 256 != 0, Cout % 128 == 0 on images at least 32 wide.  The 1x1 ping-pong kernel reads bits 0-1 */
   int32_t conv_edge;       /* bit 0: the network's last conv (GroupNorm + SiLU -> 3x3 -> <= 4 channels, NCHW fp32) runs on the streaming kernel of
                             *    conv_edge.hip instead of the generic MFMA tile kernel; bit 1: the first conv (<= 8 real input channels -> 128,
                             *    bf16) on conv3x3_in_kernel of the same file (contraction over tap x 8 channels instead of tap x padded chunk) */

@@ -206,6 +206,67 @@ def test_pingpong_conv(case, dtype, rtol, atol):
     torch.testing.assert_close(outs[0], old, rtol=rtol, atol=atol)
 
 
+PP_PRO_CASES = [
+    # B, C0, C1, H, Cout, resample, gn+silu, emb, res_mode    round 5: the in-LDS GroupNorm + SiLU prologue (PRO) and the narrow geometry (512 px x 128 ch)
+    (6, 256, 0, 16, 256, 0, True, True, 1),        # wide + prologue: ResBlock out_layers at 16x16 (unet.py:305-311), one tile per image, emb + residual
+    (300, 128, 0, 16, 256, 0, True, True, 0),      # wide + prologue, more tiles than CUs: the (a, b) rows and the padding mask switch image mid-stream
+    (40, 256, 256, 16, 256, 0, True, True, 0),     # wide + prologue over a two-source concat (unet.py:725): the (a, b) row runs across both sources
+    (33, 256, 128, 16, 256, 0, True, False, 0),    # 384 = 256 + 128 channels: GroupNorm groups of 12 straddle the source boundary
+    (9, 128, 0, 8, 256, 2, True, True, 0),         # ResBlock(up=True) in_layers: conv over nearest x2 of SiLU(GN(x)) (unet.py:332-337), 8 -> 16
+    (5, 128, 0, 32, 128, 0, True, True, 1),        # narrow + prologue: the 32x32-level ResBlock convs of the CIFAR net, two tiles per image
+    (140, 128, 0, 32, 128, 0, True, False, 1),     # narrow + prologue, more tiles than CUs
+    (20, 256, 128, 32, 128, 0, True, True, 0),     # narrow + prologue over the 384-channel concat of output_blocks (groups straddle the sources)
+    (10, 128, 64, 40, 128, 0, True, False, 2),     # narrow on a ragged 40x40 image: partial tiles in x and y, 6 chunks, RES_UP2 residual
+    (6, 128, 0, 32, 384, 0, True, True, 2),        # three 128-channel tiles per pixel tile (XCD-paired walk), RES_UP2
+    (9, 128, 0, 16, 128, 2, True, True, 0),        # narrow + prologue + nearest x2 gather (16 -> 32)
+    (7, 128, 0, 32, 128, 0, False, True, 1),       # narrow without prologue
+    (3, 64, 64, 64, 128, 0, False, False, 0),      # narrow without prologue, two sources, 64x64: 8 tiles per image
+    (2, 128, 0, 64, 128, 0, True, True, 1),        # narrow + prologue at 64x64
+]
+
+
+@pytest.mark.parametrize("case", PP_PRO_CASES)
+@pytest.mark.parametrize("dtype,rtol,atol", [(_lib.MI355_F32, 5e-5, 5e-5), (_lib.MI355_BF16, 3e-2, 3e-2)])
+def test_pingpong_conv_prologue_and_narrow(case, dtype, rtol, atol):
+    """conv3x3_pp_kernel<T, CFG, PRO> vs F.conv2d(silu(gn(cat(...)))) + emb + res (unet.py:281-285, 305-310, 725; nn.py:11-13), forced by
+    conv_pp = 2 | 4 | 8 (every eligible shape, prologue form, narrow form), and vs the kernels it replaces (conv_pp = 0)."""
+    from mi355.ops import default_ops as ops
+
+    B, C0, C1, H, Co, resample, gn, use_emb, res_mode = case
+    seed = 9500 + hash(case) % 1000
+    x = randn(seed, B, C0, H, H) * 1.3 + 0.1
+    x1 = randn(seed + 1, B, C1, H, H) * 0.7 - 0.2 if C1 else None
+    C = C0 + C1
+    sd = synth_state_dict({"in_layers.0.weight": (C,), "in_layers.0.bias": (C,), "weight": (Co, C, 3, 3), "bias": (Co,)}, seed + 2)
+    Ho = 2 * H if resample == 2 else H
+    emb = randn(seed + 3, B, Co) * 0.5 if use_emb else None
+    res = None
+    if res_mode == 1:
+        res = randn(seed + 4, B, Co, Ho, Ho)
+    elif res_mode == 2:
+        res = randn(seed + 4, B, Co, Ho // 2, Ho // 2)
+    h = x if x1 is None else torch.cat((x, x1), dim=1)
+    if gn:
+        h = F.silu(unet_ref.group_norm32(h, sd["in_layers.0.weight"], sd["in_layers.0.bias"]))
+    if resample == 2:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, sd["weight"], sd["bias"], padding=1)
+    if emb is not None:
+        ref = ref + emb[:, :, None, None]
+    if res_mode == 1:
+        ref = ref + res
+    elif res_mode == 2:
+        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+    kw = dict(resample=resample, gn=(sd["in_layers.0.weight"].to(DEV), sd["in_layers.0.bias"].to(DEV)) if gn else None, gn_silu=gn, dtype=dtype,
+              x1=x1.to(DEV) if x1 is not None else None, emb=emb.to(DEV) if emb is not None else None,
+              res=res.to(DEV) if res is not None else None, res_mode=res_mode or 1)
+    outs = [ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=14, conv_ablate=abl), **kw).cpu() for abl in (0, 64)]
+    torch.testing.assert_close(outs[0], ref, rtol=rtol, atol=atol)
+    assert torch.equal(outs[0], outs[1])
+    old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=0), **kw).cpu()
+    torch.testing.assert_close(outs[0], old, rtol=rtol, atol=atol)
+
+
 PP1_CASES = [
     # B, C0, C1, H, Cout, emb, res      prologue-free 1x1 convs with Cout % 256 == 0 on images of whole 256-pixel tiles => conv1x1_pp_kernel, forced
     (6, 256, 0, 16, 256, False, True),       # AttentionBlock proj_out: + x (unet.py:389,401), one tile per image
