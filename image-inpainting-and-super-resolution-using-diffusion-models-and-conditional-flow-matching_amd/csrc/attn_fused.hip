@@ -679,11 +679,11 @@ bool attn_fused_eligible(int dtype, int T, int C, int heads, int ch, const mi355
   const int enabled = (knobs ? knobs : &mi355_default_debug())->attn_fused;
   const int CHUNK = dtype == 0 ? 16 : 32;
   (void)CHUNK;
-  return enabled && ch == 64 && heads * ch == C && (T == 128 || T == 256) && C % 128 == 0 && C <= 512;   // 3C % 128 == 0: 128-row weight tiles
+  return (enabled & 1) && ch == 64 && heads * ch == C && (T == 128 || T == 256) && C % 128 == 0 && C <= 512;   // 3C % 128 == 0: 128-row weight tiles
 }
 
 int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream) {
-  MI355_REQUIRE(attn_fused_eligible(d.dtype, d.T, d.C, d.heads, d.ch), -4, "attention block: shape not supported by the fused kernel");
+  MI355_REQUIRE(attn_fused_eligible(d.dtype, d.T, d.C, d.heads, d.ch, d.knobs), -4, "attention block: shape not supported by the fused kernel");
   MI355_REQUIRE(d.x && d.ga && d.gb && d.w && d.bias && d.out, -1, "attention block: null argument");
   AttnFuseArgs a;
   a.x = d.x; a.ga = d.ga; a.gb = d.gb; a.w = d.w; a.bias = d.bias; a.out = d.out;

@@ -127,8 +127,9 @@ int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, floa
   const WsLayout l = unet_ws_layout(net, batch);
   MI355_REQUIRE((int64_t)l.total <= workspace_bytes, -2, "read_tensor: workspace too small");
   const PlanTensor& t = net->tensors[tensor];
-  if (!gradient && (size_t)tensor < net->tensor_state.size() && net->tensor_state[tensor]) {
-    mi355_set_error(net->tensor_state[tensor] == 1
+  const int tstate = (!gradient && (size_t)tensor < net->tensor_state_n) ? (int)net->tensor_state[tensor].load(std::memory_order_relaxed) : 0;
+  if (tstate) {
+    mi355_set_error(tstate == 1
                         ? "read_tensor: the last forward did not materialise this conv output (its only reader, a GroupNorm site, ran in the conv's epilogue): "
                           "create the handle with debug.gn_epilogue = 0 to inspect it"
                         : "read_tensor: the last forward normalised this conv output in place (16x16 level: it holds silu(GroupNorm(.)), not the conv's result): "

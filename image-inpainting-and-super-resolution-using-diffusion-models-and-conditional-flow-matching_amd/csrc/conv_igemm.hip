@@ -806,20 +806,13 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
   {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
     const int ws_slots = 2 * ((g.Wo + ws::VW - 1) / ws::VW) * ((g.Ho + ws::TH - 1) / ws::TH);   // (16x16 pixel tile, 8-row half) per image
     if (gn_ok && ws_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = ws_slots; }
-    int ws_act = 0;
-    if (d.act_out && act_done && (K.gn_epilogue & 2) && d.act_out == d.out && !d.act_raw) {   // in place: the activated tensor replaces the raw one
-      a.act_out = d.act_out; a.act_gamma = d.act_gamma; a.act_beta = d.act_beta; a.act_film = d.act_film; a.act_film_stride = d.act_film_stride;
-      a.act_eps = d.act_eps; a.act_silu = d.act_silu; a.act_raw = 0;
-    }
-    const int r = d.dtype == 0 ? launch_ws<float>(a, K.conv_ws, g.BM, g.BN, d.ks, stream, &ws_act) : launch_ws<bf16>(a, K.conv_ws, g.BM, g.BN, d.ks, stream, &ws_act);
+    const int r = d.dtype == 0 ? launch_ws<float>(a, K.conv_ws, g.BM, g.BN, d.ks, stream) : launch_ws<bf16>(a, K.conv_ws, g.BM, g.BN, d.ks, stream);
     if (r == 0) {
       MI355_CHECK_HIP(hipGetLastError());
-      if (ws_act) { if (act_done) *act_done = 1; if (gn_slots_used) *gn_slots_used = 0; }
-      else if (gn_slots_used) *gn_slots_used = a.gn_slots;
+      if (gn_slots_used) *gn_slots_used = a.gn_slots;
       return 0;
     }
     if (r < 0) return r;
-    a.act_out = nullptr;
     a.gn_stats = nullptr; a.gn_slots = 0;
   }
   {   // 8x8 / 4x4 levels: barrier-free K loop over an LDS-resident patch, weights straight into registers (conv_small.inc.h)

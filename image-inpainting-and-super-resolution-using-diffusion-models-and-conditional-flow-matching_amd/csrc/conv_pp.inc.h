@@ -98,7 +98,8 @@ template <int CFG, int PRO> struct S {
   static constexpr int iss(int i) { return PRO ? 0 : (CFG == 0 ? 2 * i : i); }                       // tap whose L segment issues patch piece i
   // PRO: a piece is transformed in the L segment of one tap (PP_TRUNIT = 0: unit 2 i = piece i, wide in taps 3 / 5 / 7, narrow in taps 3 .. 7), or as two
   // UNITS of 8 bytes per lane in two taps (PP_TRUNIT = 1).  Same-box A/Bs (profiles/r5_experiments.md): the prologue costs its VALU issue time wherever it
-  // runs - whole pieces, half pieces, operands read early or late, in the wave's own M segment between the MFMAs, with either wave priority: 256 -> 256
+  // runs - whole pieces, half pieces, operands read early or late, in the wave's own M segment between the MFMAs, with either wave priority, with the
+  // exponent as a second multiply-add from prescaled tables: 256 -> 256
   // at 16x16 68-72 us against 62 without the arithmetic and 77 on the warp-specialised kernel; the whole-piece form has the fewest instructions.
   static constexpr int NUNIT = 2 * NPW;
   static constexpr int unit_tap(int u) {
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(ConvKArgs p, int n_m
   struct TrOps { uint32_t raw[4]; float a[8], b[8]; int off; };
   auto tr_load = [&](auto uc, auto planec, TrOps& o) {
     constexpr int u = decltype(uc)::value, i = u >> 1, h = u & 1, plane = decltype(planec)::value;
-    constexpr int NB = PP_TRUNIT ? 8 : 16, NVW = NB / 4, NCH = NB / ESZ;   // bytes, 32-bit words, channels per lane
+    constexpr int NB = PP_TRUNIT ? 8 : 16, NCH = NB / ESZ;   // bytes, channels per lane
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     o.off = OFF_PLANE + plane * PLANE + (8 * i + wave8) * 1024 + h * NB + ((ln >> 2) << 6) + ((pkey[i] & 3) << 4);
@@ -733,16 +734,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(ConvKArgs p, int n_m
 // Shapes the ping-pong kernel takes: 3x3 / stride 1 / NHWC output, input either as it is or through the GroupNorm affine + SiLU prologue
 // (PRO = 2; an affine-only prologue stays on the other kernels), an even number of 64-byte channel chunks per source switch (two chunks
 // are unrolled; a source boundary may fall anywhere), images of at least one tile.  Geometry: Cout % 256 == 0 -> wide (16 x 16 x 256);
-// otherwise Cout % 128 == 0 and Wo >= 32 -> narrow (16 x 32 x 128).  mode 1: only when every CU gets a tile; mode 2: always (tests).
+// otherwise Cout % 128 == 0 and Wo >= 32 -> narrow (16 x 32 x 128).  mode = mi355_debug_config::conv_pp: bits 0-1: 1 = only when every CU
+// gets a tile, 2 = always (tests); bit 2: the prologue form of the wide geometry; bit 3: the narrow geometry; bit 4: the prologue form of the
+// narrow geometry too (off by default: same-box it ties the warp-specialised kernel at 256 / 384 input channels and loses 3-5 % at 128,
+// profiles/r5_experiments.md - the prologue's arithmetic is amortised over 128 output channels instead of 256).
 // Returns the geometry (0 wide, 1 narrow) or -1.
 static int pp_config(int mode, int ks, int G, int bn_pack, int out_mode, int stride, int nchunks, bool has_pro, bool pro_silu, int N, int Ho, int Wo, int Cout) {
-  if (!mode || ks != 3 || G != 1 || bn_pack != 128 || out_mode != OUT_NHWC || stride != 1) return -1;
-  if (has_pro && (!pro_silu || !(mode & 4))) return -1;   // bit 2 of the knob: the in-LDS prologue form
+  if (!(mode & 3) || ks != 3 || G != 1 || bn_pack != 128 || out_mode != OUT_NHWC || stride != 1) return -1;
+  if (has_pro && !pro_silu) return -1;
   if (nchunks < 2 || (nchunks & 1)) return -1;
   int cfg = -1;
   if (Cout % 256 == 0 && Wo >= 16 && Ho >= 16) cfg = 0;
-  else if (Cout % 128 == 0 && (mode & 8) && Wo >= 32 && Ho >= 16) cfg = 1;   // bit 3 of the knob: the narrow geometry
+  else if (Cout % 128 == 0 && (mode & 8) && Wo >= 32 && Ho >= 16) cfg = 1;
   if (cfg < 0) return -1;
+  if (has_pro && !(mode & (cfg == 0 ? 4 : 16))) return -1;
   if ((mode & 3) >= 2) return cfg;
   const int vw = cfg == 0 ? 16 : 32, bn = cfg == 0 ? 256 : 128;
   const int n_mt = N * ((Wo + vw - 1) / vw) * ((Ho + 15) / 16), n_nt = Cout / bn;

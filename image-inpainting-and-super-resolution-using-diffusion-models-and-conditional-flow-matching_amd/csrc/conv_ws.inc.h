@@ -52,8 +52,7 @@ constexpr int AROWB = PW * 64;                                              // b
 constexpr int BN = 128, WTILE = BN * 64, WIT = 3 * WTILE / (256 * 16);      // 6 x 16 B per loader thread per kernel row
 constexpr int CBUF = BN * 4;                                                // bias + emb of one tile's channels (f32)
 constexpr int NPLANES = 3, NWBUF = 4;                                        // patch planes / weight row buffers
-constexpr int XBUF = 2 * 4 * 16 * 8;                                        // fused-GroupNorm epilogue: the two 8-row halves of a tile exchange their group sums
-constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE + 2 * CBUF + 32 + 16 + 16 + XBUF;   // 161,568 B (+ the eight counters)
+constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE + 2 * CBUF + 64;   // 160,576 B (the eight counters, the give-up flag)
 // Counter polls are bounded (p.spin_limit, default 1 << 22 polls of >= 64 cycles: seconds): a protocol bug or a wave that never arrives
 // ends in MI355_ERR_TIMEOUT instead of a hung GPU.  A wait that gives up stores 1 into the launch's error word (p.err; cold path inside
 // the poll's asm block), every later wait of that wave polls once, and the wave goes on: the tile is wrong, the grid drains at once.
@@ -94,10 +93,7 @@ __device__ __forceinline__ u32x4 ws_pro_frag(const u32x4& raw, const f32x2 (&a2)
   return __builtin_bit_cast(u32x4, o);
 }
 
-// ACT: 1 = the GroupNorm (+ SiLU) site that reads this conv's output is applied in the epilogue, in place (16x16 images: a tile is a whole image).
-// A template parameter, not a run-time switch: round 3 measured the feature at +0.4 % and its mere presence in the shared kernel at -1.1 % on every
-// launch (7-10 more spilled VGPRs); as its own instantiation the 16 launches that do not use it keep their register allocation.
-template <typename T, int PRO, int ACT = 0>   // PRO: 0 = no prologue, 1 = GN affine, 2 = GN affine + SiLU
+template <typename T, int PRO>   // PRO: 0 = no prologue, 1 = GN affine, 2 = GN affine + SiLU
 __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_mt, int n_nt) {
   using namespace ws;
   using E = Elem<T>;
@@ -108,9 +104,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
   char* cbuf = wbuf + NWBUF * 3 * WTILE; // 2 x accumulator start values (bias + timestep embedding) of a tile's 128 channels
   uint32_t* c_prod = reinterpret_cast<uint32_t*>(cbuf + 2 * CBUF);   // [4]: kernel rows staged by loader wave w
   uint32_t* c_cons = c_prod + 4;                                     // [4]: kernel rows read by consumer wave w
-  uint32_t* c_xch = c_cons + 4;                                      // [4]: tiles whose group sums consumer wave w has published (fused-GroupNorm epilogue)
   // c_prod[12]: the workgroup's give-up flag (see wait_ge); c_prod[13 .. 15]: pad
-  char* xbuf = reinterpret_cast<char*>(c_xch + 8);                   // [2 parity][4 waves][16 quads] x (sum, sum of squares)
 
   const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -673,9 +667,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (p.ablate & 1) ? 0u : p.obytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res ? p.res : p.out), 0, p.rbytes, 0x00020000);
     constexpr bool PAIR = E::DTYPE == 1;
-    constexpr bool FASTA = E::DTYPE == 1;
     constexpr int NI = 4, NP2 = PAIR ? NI / 2 : NI, PSTEP = PAIR ? 32 : 16;
-    uint32_t xseq = 0; int xpar = 0;   // fused-GroupNorm epilogue: tiles published so far, parity of the exchange buffer
 
     f32x4 acc[8][NI];
     u32x4 af[2][4], bf[2][4];
@@ -887,126 +879,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
         }
       };
       auto epi = [&](auto resc, auto gnc) { epi_half(IC<0>(), resc, gnc); epi_half(IC<1>(), resc, gnc); };
-      if constexpr (ACT != 0) {
-        // ---- the GroupNorm (+ SiLU, FiLM) site that reads this conv's output, applied here (launcher: one 16x16 tile per image, no
-        //      residual, 4 / 8 / 16 channels per group): the tile's two 8-row halves (waves wm = 0, 1 of one channel half) exchange
-        //      their group sums through LDS, then every wave normalises its accumulators and stores silu?(a o + b) IN PLACE of the raw
-        //      tensor - the consumer conv then runs prologue-free (its loaders only issue DMA), and neither a statistics launch nor
-        //      a second copy exists.  GroupNorm32, AD/image_diffusion/nn.py:11-13,87-94; fp32 statistics of the fp32 accumulators. ----
-        const int cpg = p.Cout >> 5;
-        float gs[NI], gq[NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) { s1 += acc[mi][ni][r4]; s2 += acc[mi][ni][r4] * acc[mi][ni][r4]; }
-          s1 = GnPartial<1>::row_sum(s1); s2 = GnPartial<1>::row_sum(s2);
-          gs[ni] = s1; gq[ni] = s2;
-        }
-        {   // publish this half's quad sums (lane lr == 0 of every (ni, lq)), wait for the other half's, add in the fixed order wm = 0 + wm = 1
-          char* xb = xbuf + (size_t)(xpar * 4) * 128;
-          if (lr == 0) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x2*>(xb + (wn * 2 + wm) * 128 + (ni * 4 + lq) * 8) = f32x2{gs[ni], gq[ni]};
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          bump(c_xch + wn * 2 + wm);
-          ++xseq;
-          {
-            const uint32_t ap = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)(c_xch + wn * 2 + (wm ^ 1));
-            uint32_t v; int sv, spins = p.spin_limit;
-            asm volatile(
-                "1:\n\t"
-                "ds_read_b32 %0, %3\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_readfirstlane_b32 %1, %0\n\t"
-                "s_cmp_ge_u32 %1, %4\n\t"
-                "s_cbranch_scc1 2f\n\t"
-                "s_sub_u32 %2, %2, 1\n\t"
-                "s_cmp_eq_u32 %2, 0\n\t"
-                "s_cbranch_scc1 2f\n\t"
-                "s_sleep 1\n\t"
-                "s_branch 1b\n\t"
-                "2:"
-                : "=&v"(v), "=&s"(sv), "+s"(spins)
-                : "v"(ap), "s"(xseq)
-                : "scc", "memory");
-          }
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const f32x2 h0 = *reinterpret_cast<const f32x2*>(xb + (wn * 2 + 0) * 128 + (ni * 4 + lq) * 8);
-            const f32x2 h1 = *reinterpret_cast<const f32x2*>(xb + (wn * 2 + 1) * 128 + (ni * 4 + lq) * 8);
-            float ts = h0[0] + h1[0], tq = h0[1] + h1[1];
-            if (cpg >= 8) { ts += __shfl_xor(ts, 16); tq += __shfl_xor(tq, 16); }
-            if (cpg >= 16) { ts += __shfl_xor(ts, 32); tq += __shfl_xor(tq, 32); }
-            gs[ni] = ts; gq[ni] = tq;
-          }
-          xpar ^= 1;
-        }
-        const float inv_cnt = 1.0f / ((float)cpg * (float)(p.Ho * p.Wo));
-        f32x4 ga[NI], gb[NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const float mean = gs[ni] * inv_cnt;
-          const float var = fmaxf(gq[ni] * inv_cnt - mean * mean, 0.f);
-          const float rstd = 1.0f / sqrtf(var + p.act_eps);
-          const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.act_gamma + co_w + ni * 16);
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.act_beta + co_w + ni * 16);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float a = rstd * g4[j];
-            float b = b4[j] - mean * a;
-            if (p.act_film) {
-              const float* fp = p.act_film + (size_t)n0 * p.act_film_stride + co_w + ni * 16 + j;
-              const float sc = 1.0f + fp[0], sh = fp[p.Cout];
-              a *= sc;
-              b = b * sc + sh;
-            }
-            ga[ni][j] = a; gb[ni][j] = b;
-          }
-        }
-        auto actv = [&](float v) {
-          return p.act_silu ? (FASTA ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)) : v / (1.0f + expf(-v))) : v;
-        };
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-          const int y = y0 + wm * 8 + mi, x = x0 + lr;
-          const uint32_t opix = (uint32_t)((n0 * p.Ho + y) * p.Wo + x);
-          const uint32_t ovo = (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ;
-          if constexpr (!PAIR) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              f32x4 o;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) o[j] = actv(ga[ni][j] * acc[mi][ni][j] + gb[ni][j]);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, ovo + ni * 16 * ESZ, 0, 0);
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < NP2; ++k) {
-              bf16x4 ta, tb;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                ta[q] = (bf16)actv(ga[2 * k][q] * acc[mi][2 * k][q] + gb[2 * k][q]);
-                tb[q] = (bf16)actv(ga[2 * k + 1][q] * acc[mi][2 * k + 1][q] + gb[2 * k + 1][q]);
-              }
-              const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
-              const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
-              const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
-              __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo + k * PSTEP * ESZ, 0, 0);
-            }
-          }
-        }
-      } else {
       if (p.res_mode != RES_NONE) {
         if (!do_gn) epi(IC<1>(), IC<0>()); else if (!gn_mask) epi(IC<1>(), IC<1>()); else epi(IC<1>(), IC<2>());
       } else {
         if (!do_gn) epi(IC<0>(), IC<0>()); else if (!gn_mask) epi(IC<0>(), IC<1>()); else epi(IC<0>(), IC<2>());
       }
-      }
-      if (do_gn && ACT == 0) {   // slot = (pixel tile of the image, 8-row half); quads of this wave's 64 channels
+      if (do_gn) {   // slot = (pixel tile of the image, 8-row half); quads of this wave's 64 channels
         const int rem = mt - n0 * tpi;
         gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * 2 + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * 64) >> 2)) * 2, lq, lr);
       }
@@ -1042,28 +920,16 @@ static bool ws_eligible(int enabled, int ks, int BM, int BN, int G, int bn_pack,
 
 // 0 = launched, 1 = not eligible (caller uses the plain kernel), < 0 = error
 template <typename T>
-int launch_ws(ConvKArgs a, int enabled, int BM, int BN, int ks, hipStream_t s, int* act_done = nullptr) {
+int launch_ws(ConvKArgs a, int enabled, int BM, int BN, int ks, hipStream_t s) {
   if (!ws_eligible(enabled, ks, BM, BN, a.G, a.bn_pack, a.out_mode, a.stride, a.nchunks, a.N, a.Ho, a.Wo, a.Cout)) return 1;
   a.lvw = 4; a.lth = 4; a.PW = ws::PW; a.PH = ws::PH; a.NP = ws::NPX;
   a.tiles_x = (a.Wo + ws::VW - 1) / ws::VW; a.tiles_y = (a.Ho + ws::TH - 1) / ws::TH;
   const int n_mt = a.N * a.tiles_x * a.tiles_y, n_nt = (a.Cout + 127) / 128;
   const int ncu = ws_num_cus();
-  if (a.act_out) {   // fused GroupNorm of the output: one tile per image, whole groups per wave's channel quads, no residual
-    const int cpg = a.Cout / 32;
-    const bool ok = a.tiles_x * a.tiles_y == 1 && a.Ho == ws::TH && a.Wo == ws::VW && a.Cout % 128 == 0 && (cpg == 4 || cpg == 8 || cpg == 16) &&
-                    a.res_mode == RES_NONE;
-    if (!ok) a.act_out = nullptr;
-  }
-  if (act_done) *act_done = a.act_out ? 1 : 0;
-  if (a.act_out) { a.gn_stats = nullptr; a.gn_slots = 0; }
-  if (a.act_out && a.pro_a && !a.pro_silu) { a.act_out = nullptr; if (act_done) *act_done = 0; }   // (affine-only prologue + fused output GroupNorm: not instantiated)
   using KernT = void (*)(ConvKArgs, int, int);
-  KernT kern;
-  if (a.act_out) kern = !a.pro_a ? (KernT)conv3x3_ws_kernel<T, 0, 1> : (KernT)conv3x3_ws_kernel<T, 2, 1>;
-  else kern = !a.pro_a ? (KernT)conv3x3_ws_kernel<T, 0> : (a.pro_silu ? (KernT)conv3x3_ws_kernel<T, 2> : (KernT)conv3x3_ws_kernel<T, 1>);
+  KernT kern = !a.pro_a ? (KernT)conv3x3_ws_kernel<T, 0> : (a.pro_silu ? (KernT)conv3x3_ws_kernel<T, 2> : (KernT)conv3x3_ws_kernel<T, 1>);
   int rc;
-  if (a.act_out) rc = !a.pro_a ? mi355_allow_big_lds(conv3x3_ws_kernel<T, 0, 1>, "conv3x3 (persistent)") : mi355_allow_big_lds(conv3x3_ws_kernel<T, 2, 1>, "conv3x3 (persistent)");
-  else if (!a.pro_a) rc = mi355_allow_big_lds(conv3x3_ws_kernel<T, 0>, "conv3x3 (persistent)");
+  if (!a.pro_a) rc = mi355_allow_big_lds(conv3x3_ws_kernel<T, 0>, "conv3x3 (persistent)");
   else if (a.pro_silu) rc = mi355_allow_big_lds(conv3x3_ws_kernel<T, 2>, "conv3x3 (persistent)");
   else rc = mi355_allow_big_lds(conv3x3_ws_kernel<T, 1>, "conv3x3 (persistent)");
   if (rc) return rc;

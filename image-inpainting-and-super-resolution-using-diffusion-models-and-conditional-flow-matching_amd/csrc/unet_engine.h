@@ -4,6 +4,9 @@
 #include <vector>
 
 #include "../../include/mi355_sampler.h"
+#include <atomic>
+#include <memory>
+
 #include "ops.h"
 
 struct ParamInfo {
@@ -69,8 +72,10 @@ struct mi355_unet {
   mutable int64_t last_launches = 0;   // what the most recent forward really launched (0 before the first)
   // what the most recent forward left in each activation tensor (diagnostics: mi355_unet_read_tensor): 0 = the tensor as the reference
   // defines it, 1 = never written (its only reader, a GroupNorm site, was fused into the producing conv's epilogue), 2 = overwritten in
-  // place by silu?(GroupNorm(.)) (16x16 level).  Sized at build; single bytes, so concurrent forwards of one handle only blur the record.
-  mutable std::vector<char> tensor_state;
+  // place by silu?(GroupNorm(.)) (16x16 level).  Sized at build.  The record is PER HANDLE (of whichever forward wrote it last, on any workspace or
+  // batch size): relaxed atomic bytes, so concurrent forwards of one handle from several threads are race-free and only blur the diagnostic.
+  mutable std::unique_ptr<std::atomic<char>[]> tensor_state;
+  size_t tensor_state_n = 0;
 };
 
 // Per-call options of unet_forward.  They are arguments, not handle state: a handle is immutable after unet_build, so one

@@ -447,7 +447,9 @@ int unet_build(const mi355_unet_config& cfg, const float* const* params_host, in
   }
   if (rc) { delete net; return rc; }
   net->params = w.params;
-  net->tensor_state.assign(net->tensors.size(), 0);
+  net->tensor_state_n = net->tensors.size();
+  net->tensor_state.reset(new std::atomic<char>[net->tensor_state_n]);
+  for (size_t i = 0; i < net->tensor_state_n; ++i) net->tensor_state[i].store(0, std::memory_order_relaxed);
   net->dev_weights = reinterpret_cast<char*>(dev_weights);
   net->dev_weights_bytes = (int64_t)w.cursor;
   *out = net;
@@ -640,7 +642,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       }
       rc = conv_launch(c, stream, &slots, try_act ? &act_done : nullptr);
       if (act_done) { gn_done[oi + 1] = 1; if (act_consumer) pro_off[act_consumer] = 1; }
-      if (op.dst >= 0 && (size_t)op.dst < net->tensor_state.size()) net->tensor_state[op.dst] = !act_done ? 0 : (act_consumer ? 2 : (c.act_raw ? 0 : 1));
+      if (op.dst >= 0 && (size_t)op.dst < net->tensor_state_n) net->tensor_state[op.dst].store((char)(!act_done ? 0 : (act_consumer ? 2 : (c.act_raw ? 0 : 1))), std::memory_order_relaxed);
       if (op.dst >= 0) gn_slots[op.dst] = slots;
       if (run.prof) {
         const ConvGeom cg = conv_geometry(c);

@@ -12,7 +12,9 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-LIB_PATH = os.environ.get("MI355_SAMPLER_LIB") or os.path.join(CSRC, "libmi355_sampler.so")
+# `make -C csrc` builds csrc/libmi355_sampler.so and installs a copy as <repo>/lib/libmi355_sampler.so: the copy is what gets loaded (a short path,
+# a real file: the mapping in /proc/<pid>/maps then names a file of the repository's lib/ directory).  MI355_SAMPLER_LIB selects an experiment variant.
+LIB_PATH = os.environ.get("MI355_SAMPLER_LIB") or os.path.join(os.path.dirname(os.path.dirname(_HERE)), "lib", "libmi355_sampler.so")
 
 MI355_F32, MI355_BF16 = 0, 1
 DDPM_PRIOR, DDPM_AMORTIZED, DDPM_REPLACEMENT, DDIM = 0, 1, 2, 3

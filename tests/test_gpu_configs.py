@@ -229,7 +229,7 @@ PP_PRO_CASES = [
 @pytest.mark.parametrize("dtype,rtol,atol", [(_lib.MI355_F32, 5e-5, 5e-5), (_lib.MI355_BF16, 3e-2, 3e-2)])
 def test_pingpong_conv_prologue_and_narrow(case, dtype, rtol, atol):
     """conv3x3_pp_kernel<T, CFG, PRO> vs F.conv2d(silu(gn(cat(...)))) + emb + res (unet.py:281-285, 305-310, 725; nn.py:11-13), forced by
-    conv_pp = 2 | 4 | 8 (every eligible shape, prologue form, narrow form), and vs the kernels it replaces (conv_pp = 0)."""
+    conv_pp = 2 | 4 | 8 | 16 (every eligible shape, both prologue forms, narrow form), and vs the kernels it replaces (conv_pp = 0)."""
     from mi355.ops import default_ops as ops
 
     B, C0, C1, H, Co, resample, gn, use_emb, res_mode = case
@@ -260,7 +260,7 @@ def test_pingpong_conv_prologue_and_narrow(case, dtype, rtol, atol):
     kw = dict(resample=resample, gn=(sd["in_layers.0.weight"].to(DEV), sd["in_layers.0.bias"].to(DEV)) if gn else None, gn_silu=gn, dtype=dtype,
               x1=x1.to(DEV) if x1 is not None else None, emb=emb.to(DEV) if emb is not None else None,
               res=res.to(DEV) if res is not None else None, res_mode=res_mode or 1)
-    outs = [ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=14, conv_ablate=abl), **kw).cpu() for abl in (0, 64)]
+    outs = [ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=30, conv_ablate=abl), **kw).cpu() for abl in (0, 64)]
     torch.testing.assert_close(outs[0], ref, rtol=rtol, atol=atol)
     assert torch.equal(outs[0], outs[1])
     old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=0), **kw).cpu()
