@@ -7,7 +7,7 @@ One "step" = one pass of the hot path over one synthetic batch.  The default wor
 quantise and (N > 1) the single RCCL all-gather of the shards.  Inputs (x0, condition, weights) are resident in HBM
 before the timed region.  Weak scaling: every rank samples its own batch.
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--precision bf16|fp32]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--precision bf16|bf16x2|fp32]
     N > 1: either launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or plain
     `python bench.py --gpus N ...`: the parent then starts N fresh children of itself, one per GPU, with that environment (it has
     not touched the GPU at that point), relays rank 0's JSON line and exits with the worst child's code.
@@ -26,6 +26,7 @@ launches in one forward, on the launch stream; plus the whole-path MFMA / HBM fr
 PyTorch-CPU oracle timed on the host cores on a bounded sample; rank 0, N = 1, default workload only).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -42,6 +43,7 @@ import torch  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+BOX_REF_US = 600.0   # reference duration of the frozen box probe launch (csrc/box_probe.hip): lines are compared as value * launch_us / BOX_REF_US
 
 CIFAR = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
              channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
@@ -231,7 +233,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
     ap.add_argument("--nfe", type=int, default=0, help="network evaluations per sample (default: the workload's)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x2", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-out", default="", help="write the per-op HIP-event profile of one forward to this JSON file")
     ap.add_argument("--dry-run", action="store_true", help="launcher check: process group + shard ranges over gloo, no GPU call")
@@ -302,6 +304,20 @@ def main():
         dt = float(tt.item())
     assert out.shape[0] == B * world and out.dtype == torch.uint8
 
+    # ---- box calibration, right behind the timed region (same thermal / clock state): a FROZEN MFMA-only launch (csrc/box_probe.hip) ----
+    box = None
+    if rank == 0:
+        L = _lib.lib()
+        pw = torch.empty(int(L.mi355_box_probe_workspace_bytes()), device=dev, dtype=torch.uint8)
+        us, mhz, tfl = C.c_float(), C.c_float(), C.c_float()
+        _lib.check(L.mi355_box_probe(20, C.c_void_p(pw.data_ptr()), pw.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                     C.byref(us), C.byref(mhz), C.byref(tfl)), "mi355_box_probe")
+        box = {"kernel": "box_probe_kernel (frozen: 1.0995 TFLOP of bf16 16x16x32 MFMA on seeded register operands, no memory traffic)",
+               "launch_us": round(us.value, 2), "tflops": round(tfl.value / (us.value * 1e-6), 1), "in_kernel_clock_mhz": round(mhz.value, 0),
+               "reference_launch_us": BOX_REF_US,
+               "note": "boxes of the pool differ by several per cent for one build: compare lines of different boxes / rounds as value * launch_us / reference_launch_us"}
+        box["value_at_reference_box"] = round(B * world * a.steps / dt * us.value / BOX_REF_US, 2)
+
     # ---- roofline of the dominant kernel, HIP events around every launch of one forward (on the launch stream) ----
     # Dominant kernel (rocprofv3 --kernel-trace, profiles/): conv3x3_ws_kernel, the warp-specialised persistent 3x3 implicit-GEMM;
     # mi355_unet_profile reports its launches as tile_m == 256.  Algorithmic FLOPs = 2 * MACs of the conv.
@@ -309,9 +325,9 @@ def main():
     eng.profile(x0, tt, cond)  # warm
     recs = eng.profile(x0, tt, cond)
     conv = [r for r in recs if r["kind"] == "conv"]
-    k3 = [r for r in conv if r["ks"] == 3 and r["tile"][0] == 256]
-    dom = [r for r in k3 if r["tile"][1] != 256] or k3 or conv    # conv3x3_ws_kernel: 256 px x 128 ch tiles
-    ppk = [r for r in k3 if r["tile"][1] == 256]                  # conv3x3_pp_kernel (round 4): 256 px x 256 ch tiles
+    k3 = [r for r in conv if r["ks"] == 3 and r["tile"][0] in (256, 512)]
+    dom = [r for r in k3 if tuple(r["tile"]) == (256, 128)] or k3 or conv    # conv3x3_ws_kernel: 256 px x 128 ch tiles
+    ppk = [r for r in k3 if tuple(r["tile"]) in ((256, 256), (512, 128))]    # conv3x3_pp_kernel: 256 px x 256 ch (wide) / 512 px x 128 ch (narrow) tiles
     k1 = [r for r in conv if r["ks"] == 1]
     by = {}
     for r in recs:
@@ -320,7 +336,7 @@ def main():
     fwd_ms = sum(r["ms"] for r in recs)
     cms, cfl = by["conv"]["ms"], by["conv"]["flops"]
     dms, dfl, dby = sum(r["ms"] for r in dom), sum(r["flops"] for r in dom), sum(r["bytes"] for r in dom)
-    peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_BF16_TFLOPS if a.precision in ("bf16", "bf16x2") else PEAK_F32_TFLOPS
     achieved = dfl / (dms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     for pmc_name in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
@@ -358,6 +374,7 @@ def main():
         "flops_per_launch": dfl / len(dom),
         "algorithmic_bytes_per_launch": dby / len(dom),
         "share_of_forward": round(dms / fwd_ms, 3),
+        "box": box,
         "other_kernels": other,
         "all_conv_kernels": {"launches": len(conv), "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2), "share_of_forward": round(cms / fwd_ms, 3)},
         "forward_ms_by_kind": {k: round(v["ms"], 3) for k, v in by.items()},

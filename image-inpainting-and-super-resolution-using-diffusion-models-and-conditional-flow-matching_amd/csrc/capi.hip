@@ -399,6 +399,12 @@ int mi355_rk_interp(float* out, const float* y0, const float* y1, const float* y
   return rk_interp_launch(out, y0, y1, y_mid, f0, f1, dt, x, n, S(stream));
 }
 
+int64_t mi355_box_probe_workspace_bytes(void) { return box_probe_workspace_bytes(); }
+int mi355_box_probe(int reps, void* workspace, int64_t workspace_bytes, void* stream, float* us_per_launch, float* clock_mhz, float* tflop) {
+  if (tflop) *tflop = (float)(box_probe_flops() * 1e-12);
+  return box_probe_run(reps, workspace, workspace_bytes, S(stream), us_per_launch, clock_mhz);
+}
+
 int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw) {
   const size_t c = (size_t)max_channels + 32;
   return (int64_t)(2 * al256((size_t)batch * hw * 4 * c * 4) + al256(c * c * 9 * 4 * 2) + 4 * al256((size_t)batch * c * 4) + (1 << 20));
@@ -410,7 +416,9 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
                  int64_t workspace_bytes, void* stream) {
   const mi355_debug_config& K = debug ? *debug : mi355_default_debug();
   MI355_REQUIRE(x && w_host && y && workspace, -1, "conv2d: null argument");
-  MI355_REQUIRE(dtype == 0 || dtype == 1, -1, "conv2d: bad dtype");
+  MI355_REQUIRE(dtype == MI355_F32 || dtype == MI355_BF16 || dtype == MI355_BF16X2, -1, "conv2d: bad dtype");
+  const int wsplit = dtype == MI355_BF16X2 ? 1 : 0;   // bf16 storage, weights as hi | lo bf16 halves along K
+  if (wsplit) dtype = MI355_BF16;
   MI355_REQUIRE(stride == 1 || stride == 2, -1, "conv2d: stride must be 1 or 2");
   MI355_REQUIRE(!(stride == 2 && resample), -1, "conv2d: stride 2 cannot be combined with resampling");
   MI355_REQUIRE((x1 != nullptr) == (cin1 > 0), -1, "conv2d: x1 and cin1 go together");
@@ -421,7 +429,7 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   const int cpad = (cin + CH - 1) / CH * CH;
   const int ctot = cin + cin1, ctot_pad = cpad + cin1;
   ConvDesc d; d.dtype = dtype; d.N = batch; d.Hs = h; d.Ws = w; d.C0 = cpad; d.C1 = cin1; d.ks = ksize; d.Cout = cout;
-  d.knobs = &K;
+  d.knobs = &K; d.wsplit = wsplit;
   if (!x1 && cin <= 8) d.cin_real = cin;   // the padding channels pack_nhwc adds are zero: conv3x3_in_kernel contracts over the first slot only
   const bool pool = resample == 3;   // 2x2 average pool of the (normalised) input: a pre-pass, then a plain conv
   MI355_REQUIRE(!(pool && x1), -4, "conv2d: pooling over a channel concat is not supported");
@@ -435,7 +443,7 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   char* end = p + workspace_bytes;
   void* xin = p; p += al256((size_t)batch * h * w * cpad * esz);
   void* xin1 = p; if (x1) p += al256((size_t)batch * h * w * cin1 * esz);
-  void* wdev = p; const size_t wbytes = conv_packed_weight_bytes(dtype, cout, ctot, ksize); p += al256(wbytes);
+  void* wdev = p; const size_t wbytes = conv_packed_weight_bytes(dtype, cout, ctot, ksize, wsplit); p += al256(wbytes);
   float* bdev = reinterpret_cast<float*>(p); p += al256((size_t)cout * 4);
   float* ga = reinterpret_cast<float*>(p); p += al256((size_t)batch * ctot_pad * 4);
   float* gb = reinterpret_cast<float*>(p); p += al256((size_t)batch * ctot_pad * 4);
@@ -451,7 +459,7 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   if (x1 && (rc = pack_nhwc_launch(dtype, x1, cin1, nullptr, 0, batch, h * w, cin1, xin1, s))) return rc;
   if (res && (rc = pack_nhwc_launch(dtype, res, cout, nullptr, 0, batch, Hr * Wr, cout, rin, s))) return rc;
   std::vector<char> packed(wbytes);
-  conv_pack_weights(dtype, w_host, cout, ctot, ksize, packed.data());
+  conv_pack_weights(dtype, w_host, cout, ctot, ksize, packed.data(), wsplit);
   MI355_CHECK_HIP(hipMemcpyAsync(wdev, packed.data(), wbytes, hipMemcpyHostToDevice, s));
   if (bias_host) MI355_CHECK_HIP(hipMemcpyAsync(bdev, bias_host, (size_t)cout * 4, hipMemcpyHostToDevice, s));
   if (gn_gamma) {

@@ -278,7 +278,7 @@ int launch1(const K1Args& a, dim3 grid, size_t lds, hipStream_t s) {
 
 // Returns 1 if this conv is not eligible (caller falls back to the generic implicit-GEMM kernel), 0 on launch, <0 on error.
 int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
-  if (d.ks != 1 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC) return 1;
+  if (d.ks != 1 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.wsplit) return 1;   // (hi / lo split weights: the ping-pong / generic kernels)
   {   // prologue-free, 256-channel output tiles, whole 256-pixel tiles per image: the streaming ping-pong kernel (conv_pp1.inc.h)
     const int r = conv1x1_pp_try_launch(d, stream, gn_slots_used);
     if (r <= 0) return r;

@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256, 4) conv3x3_in_kernel(InArgs p) {
 // 0 = launched, 1 = not eligible (the caller goes on to the generic kernel), < 0 = error.  Switch: mi355_debug_config::conv_edge.
 int conv_out_try_launch(const ConvDesc& d, hipStream_t stream) {
   const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
-  if (!(K.conv_edge & 1)) return 1;
+  if (!(K.conv_edge & 1) || d.wsplit) return 1;   // (hi / lo split weights: the generic kernel)
   if (d.ks != 3 || d.mode != CONV_UNIT || d.out_mode != OUT_NCHW_F32 || d.src1 || d.res || d.emb || !d.pro_a || d.Cout > 4 || d.Cout < 1) return 1;
   const int V = d.dtype == 0 ? 4 : 8, esz = d.dtype == 0 ? 4 : 2;
   const int FPP = d.C0 / V;
@@ -344,7 +344,7 @@ int conv_out_try_launch(const ConvDesc& d, hipStream_t stream) {
 // The first conv (see conv3x3_in_kernel).  0 = launched, 1 = not eligible, < 0 = error.  Switch: mi355_debug_config::conv_edge bit 1.
 int conv_in_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
-  if (!(K.conv_edge & 2)) return 1;
+  if (!(K.conv_edge & 2) || d.wsplit) return 1;
   if (d.dtype != 1 || d.ks != 3 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.src1 || d.res || d.emb || d.pro_a || d.act_out) return 1;
   if (d.cin_real < 1 || d.cin_real > 8 || d.C0 != 32 || d.Cout != 128 || conv_tile_n(d.Cout) != 128 || !d.bias) return 1;
   if (d.Hs % 16 != 0 || d.Ws % 16 != 0) return 1;

@@ -31,7 +31,8 @@ constexpr int PROW = 96;   // bytes per patch pixel row in LDS (64 data + 32 pad
 
 struct ConvKArgs {
   const void* src0; const void* src1;
-  int C0, C1, Cin, nchunks;
+  int C0, C1, Cin, nchunks;          // nchunks: 64-byte K chunks of the packed weights (2 x nreal with hi / lo split weights, else nreal)
+  int nreal;                         // 64-byte channel chunks of the activations: weight chunk c contracts with activation chunk c mod nreal
   int N, Hs, Ws, Hc, Wc, Ho, Wo;
   int mode, pad, stride;
   const float* pro_a; const float* pro_b; int pro_silu;
@@ -80,6 +81,9 @@ __device__ __forceinline__ unsigned long long conv_stamp() {
 #endif
 
 template <int I> struct IC { static constexpr int value = I; };
+
+// activation chunk of weight chunk c (hi / lo split weights: the second half of the K loop runs over the same activations again)
+__device__ __forceinline__ int src_chunk(const ConvKArgs& p, int c) { return c >= p.nreal ? c - p.nreal : c; }
 
 template <bool FAST> __device__ __forceinline__ float silu_fast(float v) {
   if (FAST) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
@@ -134,6 +138,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
   int sidx[PIT];        // source pixel index, -1 = zero padding / out of range
   uint32_t voff[PIT];   // byte offset of the fragment in the CURRENT source tensor (>= size when invalid)
   uint32_t vmask = 0;
+  bool vsrc0 = true;    // voff currently addresses the first source
   {
     const int cy0 = y0 * p.stride - p.pad, cx0 = x0 * p.stride - p.pad;
     const float inv_pimg = 1.0f / (float)pimg, inv_pw = 1.0f / (float)p.PW;
@@ -205,18 +210,19 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
 #ifdef CONV_STAMPS
     if (p.ablate & 16) return;
 #endif
-    const int cb = c * CHUNK;
+    const int cb = src_chunk(p, c) * CHUNK;
     {
-      if (cb < p.C0) {
-        const uint32_t so = cb * ESZ;
+      const bool first = cb < p.C0;
+      if (first != vsrc0) {   // the chunk stream enters the other source (skip concat; with hi / lo split weights it comes back to the first): re-base the fragment offsets
+        vsrc0 = first;
+#pragma unroll
+        for (int u = 0; u < PIT; ++u) voff[u] = sidx[u] >= 0 ? (uint32_t)sidx[u] * (uint32_t)((first ? p.C0 : p.C1) * ESZ) + fq * 16 : (first ? p.bytes0 : p.bytes1);
+      }
+      const uint32_t so = (first ? cb : cb - p.C0) * ESZ;
+      if (first) {
 #pragma unroll
         for (int u = 0; u < PIT; ++u) raw[pl][u] = buf_load16(rs0, voff[u], so);
       } else {
-        if (cb == p.C0) {  // first chunk of the second (skip-concat) source: re-base the fragment offsets once
-#pragma unroll
-          for (int u = 0; u < PIT; ++u) voff[u] = sidx[u] >= 0 ? (uint32_t)sidx[u] * (uint32_t)(p.C1 * ESZ) + fq * 16 : p.bytes1;
-        }
-        const uint32_t so = (cb - p.C0) * ESZ;
 #pragma unroll
         for (int u = 0; u < PIT; ++u) raw[pl][u] = buf_load16(rs1, voff[u], so);
       }
@@ -656,9 +662,9 @@ int conv_tile_n(int Cout) {
 
 static inline int chunk_of(int dtype) { return dtype == 0 ? 16 : 32; }
 
-size_t conv_packed_weight_bytes(int dtype, int Cout, int Cin, int ks) {
+size_t conv_packed_weight_bytes(int dtype, int Cout, int Cin, int ks, int split) {
   const int BN = conv_tile_n(Cout), CH = chunk_of(dtype);
-  const size_t nt = (Cout + BN - 1) / BN, nc = (Cin + CH - 1) / CH;
+  const size_t nt = (Cout + BN - 1) / BN, nc = (size_t)((Cin + CH - 1) / CH) * (split ? 2 : 1);
   return nt * nc * ks * ks * (size_t)BN * 64;
 }
 
@@ -668,23 +674,26 @@ static inline uint16_t f2bf(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-void conv_pack_weights(int dtype, const float* w, int Cout, int Cin, int ks, void* dst) {
+void conv_pack_weights(int dtype, const float* w, int Cout, int Cin, int ks, void* dst, int split) {
   const int BN = conv_tile_n(Cout), CH = chunk_of(dtype), V = CH / 4, esz = dtype == 0 ? 4 : 2;
-  const int nt = (Cout + BN - 1) / BN, nc = (Cin + CH - 1) / CH, ntaps = ks * ks;
+  const int nt = (Cout + BN - 1) / BN, nr = (Cin + CH - 1) / CH, nc = nr * (split && dtype == 1 ? 2 : 1), ntaps = ks * ks;
   char* out = reinterpret_cast<char*>(dst);
-  memset(out, 0, conv_packed_weight_bytes(dtype, Cout, Cin, ks));
+  memset(out, 0, conv_packed_weight_bytes(dtype, Cout, Cin, ks, split));
   for (int t = 0; t < nt; ++t)
     for (int c = 0; c < nc; ++c)
       for (int tap = 0; tap < ntaps; ++tap) {
         char* tile = out + (((size_t)t * nc + c) * ntaps + tap) * (size_t)BN * 64;
+        const bool lo = c >= nr;               // second half of the K loop: the rounding residual of the first half's weights
         for (int row = 0; row < BN; ++row) {
           const int co = t * BN + row;
           if (co >= Cout) break;
           for (int kl = 0; kl < CH; ++kl) {
-            const int ci = c * CH + kl;
+            const int ci = (lo ? c - nr : c) * CH + kl;
             if (ci >= Cin) break;
-            const float v = w[((size_t)co * Cin + ci) * ntaps + tap];
+            float v = w[((size_t)co * Cin + ci) * ntaps + tap];
+            if (lo) v = v - bf2f(f2bf(v));
             const int q = kl / V, e = kl % V;
             char* dstp = tile + row * 64 + 16 * (q ^ ((row >> 1) & 3)) + e * esz;
             if (dtype == 0) memcpy(dstp, &v, 4);
@@ -715,7 +724,7 @@ ConvGeom conv_geometry(const ConvDesc& d) {
   const int CH = d.dtype == 0 ? 16 : 32;
   const mi355_debug_config& Kg = d.knobs ? *d.knobs : mi355_default_debug();
   if (d.C0 % CH == 0 && d.C1 % CH == 0) {
-    const int pc = pp_config(Kg.conv_pp, d.ks, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.pro_a != nullptr, d.pro_silu != 0, d.N, g.Ho, g.Wo, d.Cout);
+    const int pc = pp_config(Kg.conv_pp, d.ks, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH * (d.wsplit ? 2 : 1), d.pro_a != nullptr, d.pro_silu != 0, d.N, g.Ho, g.Wo, d.Cout);
     if (pc >= 0) {   // ping-pong kernel (conv_pp.inc.h): 256 px x 256 ch or 512 px x 128 ch tiles
       r.BM = pc == 0 ? 256 : 512; r.BN = pc == 0 ? 256 : 128;
       r.lds_bytes = pc == 0 ? pp::D<0>::lds_bytes(d.pro_a != nullptr) : pp::D<1>::lds_bytes(d.pro_a != nullptr);
@@ -723,7 +732,7 @@ ConvGeom conv_geometry(const ConvDesc& d) {
     }
   }
   if (d.C0 % CH == 0 && d.C1 % CH == 0 &&
-      ws_eligible((d.knobs ? d.knobs : &mi355_default_debug())->conv_ws, d.ks, g.BM, g.BN, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH, d.N, g.Ho, g.Wo, d.Cout)) {
+      ws_eligible((d.knobs ? d.knobs : &mi355_default_debug())->conv_ws, d.ks, g.BM, g.BN, g.G, g.bn_pack, d.out_mode, g.stride, (d.C0 + d.C1) / CH * (d.wsplit ? 2 : 1), d.N, g.Ho, g.Wo, d.Cout)) {
     r.BM = 256; r.lds_bytes = ws::LDS_BYTES;   // warp-specialised persistent kernel: 16 x 16 pixel tiles (grid_m / grid_n stay the plain launch's: workspace sizing)
   }
   return r;
@@ -755,14 +764,15 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
   MI355_REQUIRE(g.lds <= 160 * 1024, -4, "conv: LDS budget exceeded");
   MI355_REQUIRE(g.pit <= g.pit_t, -4, "conv: input patch too large for the staging loops");
   ConvKArgs a{};
-  a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = Cin / CH;
+  MI355_REQUIRE(!d.wsplit || d.dtype == 1, -1, "conv: hi / lo split weights are a bf16 mode");
+  a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nreal = Cin / CH; a.nchunks = a.nreal * (d.wsplit ? 2 : 1);
   a.N = d.N; a.Hs = d.Hs; a.Ws = d.Ws; a.Hc = g.Hc; a.Wc = g.Wc; a.Ho = g.Ho; a.Wo = g.Wo;
   a.mode = d.mode; a.pad = g.pad; a.stride = g.stride;
   a.pro_a = d.pro_a; a.pro_b = d.pro_b; a.pro_silu = d.pro_silu;
   a.w = d.w; a.bias = d.bias; a.Cout = d.Cout; a.bn_pack = g.bn_pack;
   const size_t esz = d.dtype == 0 ? 4 : 2;
   const size_t b0 = (size_t)d.N * d.Hs * d.Ws * d.C0 * esz, b1 = (size_t)d.N * d.Hs * d.Ws * d.C1 * esz;
-  const size_t wb = conv_packed_weight_bytes(d.dtype, d.Cout, Cin, d.ks);
+  const size_t wb = conv_packed_weight_bytes(d.dtype, d.Cout, Cin, d.ks, d.wsplit);
   MI355_REQUIRE(b0 < 0xFFFF0000ull && b1 < 0xFFFF0000ull && wb < 0xFFFF0000ull, -4,
                 "conv: a source tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb;

@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(ConvKArgs p, int n_m
   ps_setup(t_first);
   auto issue_patch = [&](auto ic, auto planec, int sc) {   // piece i of chunk sc (of the streamed tile) -> plane
     constexpr int i = decltype(ic)::value, plane = decltype(planec)::value;
-    const int cb = sc * CHUNK;
+    const int cb = src_chunk(p, sc) * CHUNK;
     const bool first = cb < p.C0;
     const uint32_t so = (uint32_t)((first ? cb : cb - p.C0) * ESZ);
     char* dst = smem + OFF_PLANE + plane * PLANE + (8 * i + wave8) * 1024;
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(ConvKArgs p, int n_m
   const uint32_t abvo = PRO ? ((uint32_t)lane < (uint32_t)CHUNK ? (uint32_t)lane * 4u : abytes) : 0u;
   auto issue_ab = [&](int sc) {
     if constexpr (PRO != 0) {
-      const uint32_t so = (uint32_t)(ps_n0 * p.Cin + sc * CHUNK) * 4u;
+      const uint32_t so = (uint32_t)(ps_n0 * p.Cin + src_chunk(p, sc) * CHUNK) * 4u;
       char* dst = smem + OFF_AB + wave8 * pp::ABUF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (__attribute__((address_space(3))) void*)dst, 4, abvo, so, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)(dst + 256), 4, abvo, so, 0, 0);

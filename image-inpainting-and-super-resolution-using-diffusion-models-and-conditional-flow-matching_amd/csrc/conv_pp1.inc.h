@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
     for (int q = 0; q < PB; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(dw + q * 1024), 16, wvo0 + q * 1024u, ws_soff, 0, 0);
     ws_soff += 8192u;
-    const int cb = s_chunk * CHUNK;
+    const int cb = src_chunk(p, s_chunk) * CHUNK;
     const bool first = cb < p.C0;
     const uint32_t so = (uint32_t)((first ? cb : cb - p.C0) * ESZ);
     char* da = smem + OFF_A + ring * TAPA + (PA * wave8) * 1024;
@@ -303,21 +303,21 @@ static int pp1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_u
   if (d.Cout % 128 != 0 || d.C0 % CH != 0 || d.C1 % CH != 0 || conv_tile_n(d.Cout) != 128) return 1;
   const int wide = d.Cout % 256 == 0;
   const int BM = wide ? 256 : 512, BN = wide ? 256 : 128;
-  const int Cin = d.C0 + d.C1, nchunks = Cin / CH, HW = d.Hs * d.Ws;
+  const int Cin = d.C0 + d.C1, nreal = Cin / CH, nchunks = nreal * (d.wsplit ? 2 : 1), HW = d.Hs * d.Ws;
   // (four chunks: the old stationary-tile kernel ties - 128 -> 256 at 16x16: 13.4 vs 13.9 us - and stays)
   if (nchunks < 8 || (nchunks & 3) || (HW % BM) != 0) return 1;
   if (d.res && d.res_mode != RES_SAME) return 1;
   const int n_mt = (int)((long)d.N * HW / BM), n_nt = d.Cout / BN;
   if ((K.conv_pp & 3) < 2 && n_mt * n_nt < ws_num_cus()) return 1;
   ConvKArgs a{};
-  a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = nchunks;
+  a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nchunks = nchunks; a.nreal = nreal;
   a.N = d.N; a.Hs = d.Hs; a.Ws = d.Ws; a.Hc = d.Hs; a.Wc = d.Ws; a.Ho = d.Hs; a.Wo = d.Ws;
   a.w = d.w; a.bias = d.bias; a.Cout = d.Cout; a.bn_pack = 128;
   a.emb = d.emb; a.emb_stride = d.emb_stride;
   a.res = d.res; a.res_mode = d.res ? RES_SAME : RES_NONE; a.Hr = d.Hs; a.Wr = d.Ws;
   a.out = d.out; a.out_mode = OUT_NHWC;
   const size_t b0 = (size_t)d.N * HW * d.C0 * esz, b1 = (size_t)d.N * HW * d.C1 * esz, ob = (size_t)d.N * HW * d.Cout * esz;
-  const size_t wb = conv_packed_weight_bytes(d.dtype, d.Cout, Cin, 1);
+  const size_t wb = conv_packed_weight_bytes(d.dtype, d.Cout, Cin, 1, d.wsplit);
   MI355_REQUIRE(b0 < 0xFFFF0000ull && b1 < 0xFFFF0000ull && wb < 0xFFFF0000ull && ob < 0xFFFF0000ull, -4,
                 "conv1x1: a tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb; a.obytes = (uint32_t)ob; a.rbytes = d.res ? (uint32_t)ob : 0u;

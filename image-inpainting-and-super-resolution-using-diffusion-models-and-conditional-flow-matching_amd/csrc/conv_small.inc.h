@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Arg
     u32x4 raw[NCHP][PITU];
 #pragma unroll
     for (int cl = 0; cl < NCHP; ++cl) {
-      const int cb = (ph * g.chp + cl) * CHUNK;
+      const int cb = src_chunk(p, ph * g.chp + cl) * CHUNK;
       const bool live = cl < g.chp, first = cb < p.C0;
 #pragma unroll
       for (int u = 0; u < PITU; ++u) {

@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
       constexpr int ky = decltype(kyc)::value;
       if (pt_t >= ntp) return 0;
       if constexpr (WS_ABLATE & 16) return 0;
-      const int cb = pt_c * CHUNK;
+      const int cb = src_chunk(p, pt_c) * CHUNK;
       const bool first = cb < p.C0;
       const uint32_t so = (uint32_t)((first ? cb : cb - p.C0) * ESZ);
       char* pl = pbuf + pt_plane * PLANE;
@@ -490,14 +490,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
     // i.e. vmcnt(0) at every use, which would drain the whole run-ahead.
     auto issue_frag = [&](auto uc) {
       constexpr int u = decltype(uc)::value;
-      const int cb = ld_c * CHUNK;
+      const int cb = src_chunk(p, ld_c) * CHUNK;
       const bool first = cb < p.C0;
       if constexpr (!(WS_ABLATE & 16)) raw[u] = buf_load16(first ? rs0 : rs1, first ? voff0[u] : voff1[u], (first ? cb : cb - p.C0) * ESZ);
     };
     auto issue_ab = [&]() {
       if constexpr (PRO) {
-        const float* ap = p.pro_a + (size_t)n0_ld * p.Cin + ld_c * CHUNK + fq * V;
-        const float* bp = p.pro_b + (size_t)n0_ld * p.Cin + ld_c * CHUNK + fq * V;
+        const float* ap = p.pro_a + (size_t)n0_ld * p.Cin + src_chunk(p, ld_c) * CHUNK + fq * V;
+        const float* bp = p.pro_b + (size_t)n0_ld * p.Cin + src_chunk(p, ld_c) * CHUNK + fq * V;
 #pragma unroll
         for (int j = 0; j < V / 2; ++j) { pan[j] = *reinterpret_cast<const f32x2*>(ap + 2 * j); pbn[j] = *reinterpret_cast<const f32x2*>(bp + 2 * j); }
       }

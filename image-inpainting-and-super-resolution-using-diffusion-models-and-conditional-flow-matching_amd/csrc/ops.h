@@ -45,6 +45,8 @@ struct ConvDesc {
   const float* act_film = nullptr; int act_film_stride = 0; float act_eps = 1e-5f; int act_silu = 0, act_raw = 1;
   const void* warm = nullptr; uint32_t warm_bytes = 0;
   int cin_real = 0;                         // > 0: only the first cin_real channels of src0 are non-zero (the network's first conv: in_channels padded to a chunk)
+  int wsplit = 0;                           // 1 (bf16x2 precision): w holds [bf16(w) | bf16(w - bf16(w))] along K (twice the chunks): the contraction runs over the
+                                            // input channels twice, once against each half - fp32 accumulation of both, activations read (not stored) twice
 };
 
 struct ConvGeom {
@@ -54,10 +56,11 @@ struct ConvGeom {
 };
 ConvGeom conv_geometry(const ConvDesc& d);
 // bytes of the packed weight image for a [Cout][Cin][ks][ks] filter
-size_t conv_packed_weight_bytes(int dtype, int Cout, int Cin, int ks);
+size_t conv_packed_weight_bytes(int dtype, int Cout, int Cin, int ks, int split = 0);
 int conv_tile_n(int Cout);
 // host-side packing: w_host [Cout][Cin][ks][ks] fp32 (Cin = logical input channels; padded to a chunk)
-void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks, void* dst_host);
+// split = 1 (bf16 only): [hi | lo] halves along K, hi = bf16(w), lo = bf16(w - hi); the chunk count doubles
+void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks, void* dst_host, int split = 0);
 int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr, int* act_done = nullptr);
 // 1x1 GEMM with a stationary activation tile (conv1x1.hip): 0 = launched, 1 = not eligible, <0 = error
 int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
@@ -153,6 +156,11 @@ int guidance_seed_launch(const float* x, const float* eps, const float* cond, fl
 int guidance_update_launch(float* x, const float* g_x, const float* vjp, float scale, int apply, float* update, int64_t n, hipStream_t s);
 // out[n][c][hw] (NCHW fp32, c < count) = in[n][hw][c0 + c] (NHWC T, row stride `stride`)
 int unpack_channels_launch(int dtype, const void* in, int N, int HW, int stride, int c0, int count, float* out, hipStream_t s);
+
+// ---- box calibration probe (box_probe.hip: frozen) ------------------------------------------------------------------------------
+int64_t box_probe_workspace_bytes();
+double box_probe_flops();
+int box_probe_run(int reps, void* workspace, int64_t workspace_bytes, hipStream_t s, float* us_per_launch, float* clock_mhz);
 
 // ---- small fp32 ops -----------------------------------------------------------------------------------
 int timestep_embedding_launch(const float* t, int B, int dim, float max_period, float* out, hipStream_t s);

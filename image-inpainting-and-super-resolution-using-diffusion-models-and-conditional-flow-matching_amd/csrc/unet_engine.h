@@ -68,6 +68,7 @@ struct mi355_unet {
   int in_tensor = -1, out_channels = 0;
   // stats per image
   double conv_flops = 0, attn_flops = 0, act_bytes = 0, weight_bytes = 0;
+  int wsplit = 0;         // MI355_BF16X2: conv / qkv weights packed as hi | lo bf16 halves along K (ConvDesc::wsplit)
   int64_t launches = 0;   // device launches of one forward as planned (an upper bound: a GroupNorm pass a conv epilogue absorbed is not launched)
   mutable int64_t last_launches = 0;   // what the most recent forward really launched (0 before the first)
   // what the most recent forward left in each activation tensor (diagnostics: mi355_unet_read_tensor): 0 = the tensor as the reference

@@ -67,9 +67,9 @@ struct Walker {
   size_t put_conv(const std::string& name, int Cout, int Cin, int ks, bool conv1d) {
     std::vector<int64_t> shape = conv1d ? std::vector<int64_t>{Cout, Cin, 1} : std::vector<int64_t>{Cout, Cin, ks, ks};
     const float* p = P(name, shape);
-    size_t bytes = conv_packed_weight_bytes(dtype, Cout, Cin, ks);
+    size_t bytes = conv_packed_weight_bytes(dtype, Cout, Cin, ks, net->wsplit);
     size_t o = alloc(bytes);
-    if (!dry && p) conv_pack_weights(dtype, p, Cout, Cin, ks, blob.data() + o);
+    if (!dry && p) conv_pack_weights(dtype, p, Cout, Cin, ks, blob.data() + o, net->wsplit);
     net->weight_bytes += (double)Cout * Cin * ks * ks * esz;
     return o;
   }
@@ -213,7 +213,7 @@ struct Walker {
     }
     const int yn = add_gn(x, -1, p + ".norm.weight", p + ".norm.bias", -1, 0);
     const double Tn_ = (double)T(x).H * T(x).W;
-    if (yn < 0 && !cfg.differentiable && attn_fused_eligible(dtype, T(x).H * T(x).W, C, heads, ch, &net->knobs)) {
+    if (yn < 0 && !cfg.differentiable && !net->wsplit && attn_fused_eligible(dtype, T(x).H * T(x).W, C, heads, ch, &net->knobs)) {
       // norm-apply + qkv 1x1 + attention in one kernel (attn_fused.hip): the [T, 3C] qkv tensor never exists
       PlanOp op; op.kind = OP_ATTN_FUSED; op.src0 = x; op.heads = heads; op.ch = ch; op.Cout = 3 * C;
       op.w_off = put_conv(p + ".qkv.weight", 3 * C, C, 1, true);
@@ -330,7 +330,8 @@ struct Walker {
 };
 
 int check_cfg(const mi355_unet_config& c) {
-  MI355_REQUIRE(c.dtype == MI355_F32 || c.dtype == MI355_BF16, -1, "unet: dtype must be MI355_F32 or MI355_BF16");
+  MI355_REQUIRE(c.dtype == MI355_F32 || c.dtype == MI355_BF16 || c.dtype == MI355_BF16X2, -1, "unet: dtype must be MI355_F32, MI355_BF16 or MI355_BF16X2");
+  MI355_REQUIRE(!(c.dtype == MI355_BF16X2 && c.differentiable), -4, "unet: the hi / lo weight split (MI355_BF16X2) has no backward pass");
   MI355_REQUIRE(c.n_channel_mult >= 1 && c.n_channel_mult <= 8 && c.n_attention_ds >= 0 && c.n_attention_ds <= 8, -1, "unet: bad config arrays");
   MI355_REQUIRE(c.model_channels % 32 == 0 && c.model_channels > 0, -4, "unet: model_channels must be a multiple of 32 (GroupNorm32 + 64-byte channel chunks)");
   MI355_REQUIRE(c.in_channels > 0 && c.in_channels <= 32 && c.out_channels > 0 && c.out_channels <= 32, -4, "unet: in/out channels must be in 1..32");
@@ -410,11 +411,14 @@ int unet_enumerate_params(const mi355_unet_config& cfg, std::vector<ParamInfo>& 
 }
 
 static int run_walker(const mi355_unet_config& cfg, const float* const* host, mi355_unet* net, Walker& w) {
-  w.cfg = cfg; w.dtype = cfg.dtype; w.esz = cfg.dtype == 0 ? 4 : 2; w.CH = cfg.dtype == 0 ? 16 : 32;
+  // MI355_BF16X2 = bf16 storage and MFMAs with every conv / qkv weight held as hi + lo bf16 halves: from here on the plan is a bf16 plan with wsplit set
+  net->wsplit = cfg.dtype == MI355_BF16X2 ? 1 : 0;
+  w.cfg = cfg; if (net->wsplit) w.cfg.dtype = MI355_BF16;
+  w.dtype = w.cfg.dtype; w.esz = w.dtype == 0 ? 4 : 2; w.CH = w.dtype == 0 ? 16 : 32;
   w.dry = host == nullptr; w.host = host; w.net = net;
   if (int rc = unet_enumerate_params(cfg, w.params)) return rc;
   for (size_t i = 0; i < w.params.size(); ++i) w.pidx[w.params[i].name] = (int)i;
-  net->cfg = cfg;
+  net->cfg = w.cfg;
   net->knobs = cfg.debug ? *cfg.debug : mi355_default_debug();
   net->cfg.debug = nullptr;
   if (w.walk() != 0 || !w.err.empty()) { mi355_set_error("unet plan: " + w.err); return -4; }
@@ -559,7 +563,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     if (!(warm_mask & bit) || oi + 1 >= net->ops.size() || net->ops[oi + 1].kind != OP_CONV) return;
     const PlanOp& nx = net->ops[oi + 1];
     const int cin = net->tensors[nx.src0].C + (nx.src1 >= 0 ? net->tensors[nx.src1].C : 0);
-    wp = W + nx.w_off; wb = (uint32_t)conv_packed_weight_bytes(dtype, nx.Cout, cin, nx.ks);
+    wp = W + nx.w_off; wb = (uint32_t)conv_packed_weight_bytes(dtype, nx.Cout, cin, nx.ks, net->wsplit);
   };
   for (const PlanOp& op : net->ops) {
     mi355_op_profile r{};
@@ -595,7 +599,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       r.bytes = (double)B * s0.H * s0.W * (s0.C + C1) * esz * (op.dst >= 0 ? 2 : 1);
     } else if (op.kind == OP_CONV) {
       ConvDesc c; c.dtype = dtype; c.src0 = TP(op.src0); c.C0 = s0.C; c.src1 = TP(op.src1); c.C1 = C1;
-      c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks;
+      c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks; c.wsplit = net->wsplit;
       const size_t oi = (size_t)(&op - net->ops.data());
       if (op.use_pro && !pro_off[oi]) { c.pro_a = F(l.gna); c.pro_b = F(l.gnb); c.pro_silu = op.pro_silu; }
       if (op.use_pro && !pro_off[oi] && op.gn_site >= 0) {

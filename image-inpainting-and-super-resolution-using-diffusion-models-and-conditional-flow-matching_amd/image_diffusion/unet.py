@@ -178,7 +178,8 @@ class UNetModel(nn.Module):
 
     # ---- engine management -------------------------------------------------------------------
     def set_precision(self, precision: str):
-        """'bf16' (bf16 storage + bf16 MFMA, fp32 accumulate / GN / softmax) or 'fp32' (exact f32 MFMA)."""
+        """'bf16' (bf16 storage + bf16 MFMA, fp32 accumulate / GN / softmax), 'bf16x2' (the same with every conv / qkv weight as hi + lo bf16
+        halves: no weight rounding, twice the MFMAs) or 'fp32' (exact f32 MFMA; the reference is fp32 end to end, unet.py:559,719)."""
         self.precision = precision
         self._engine = None
         self._dengine = None

@@ -16,7 +16,7 @@ CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 # a real file: the mapping in /proc/<pid>/maps then names a file of the repository's lib/ directory).  MI355_SAMPLER_LIB selects an experiment variant.
 LIB_PATH = os.environ.get("MI355_SAMPLER_LIB") or os.path.join(os.path.dirname(os.path.dirname(_HERE)), "lib", "libmi355_sampler.so")
 
-MI355_F32, MI355_BF16 = 0, 1
+MI355_F32, MI355_BF16, MI355_BF16X2 = 0, 1, 2   # BF16X2: bf16 storage / MFMAs, conv + qkv weights as hi + lo bf16 halves (weight rounding removed)
 DDPM_PRIOR, DDPM_AMORTIZED, DDPM_REPLACEMENT, DDIM = 0, 1, 2, 3
 
 
@@ -136,6 +136,8 @@ SIGNATURES = {
     "mi355_rk_sqnorm": (_I, [_VP, _VP, _VP, _VP, _F, _F, _I64, _VP, _VP]),
     "mi355_rk_interp": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _I64, _VP]),
     "mi355_op_workspace_bytes": (_I64, [_I, _I, _I]),
+    "mi355_box_probe_workspace_bytes": (_I64, []),
+    "mi355_box_probe": (_I, [_I, _VP, _I64, _VP, _FP, _FP, _FP]),
     "mi355_conv2d": (_I, [_VP, _VP, _I, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _I, C.POINTER(DebugConfigC), _VP,
                           _I64, _VP]),
     "mi355_qkv_attention": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I64, _VP]),

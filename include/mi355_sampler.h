@@ -35,9 +35,12 @@ extern "C" {
 /* compute type of the contraction path */
 #define MI355_F32 0  /* fp32 storage, exact f32 MFMA (v_mfma_f32_16x16x4_f32): tight-parity mode   */
 #define MI355_BF16 1 /* bf16 storage + bf16 MFMA, fp32 accumulate; GN stats / softmax / x state fp32 */
+#define MI355_BF16X2 2 /* as MI355_BF16 with every conv / qkv weight held as two bf16 halves, hi = bf16(w) and lo = bf16(w - hi), multiplied by the
+                        * same bf16 activations and accumulated in fp32 (twice the MFMAs): the weight rounding - 94 % of bf16 mode's distance to
+                        * fp32 mode (profiles/r4_quality_delta.json) - is gone; mi355_unet_config::dtype and the test ops' dtype accept it */
 
-/* ABI version = 100 * major + minor.  The minor number counts additive changes; 103 (round 5): conv_pp became a bit mask (bits 2, 3: the
- * prologue and narrow forms of the ping-pong kernel).  102 (round 4): mi355_debug_config gained conv_pp and
+/* ABI version = 100 * major + minor.  The minor number counts additive changes; 103 (round 5): conv_pp became a bit mask (bits 2, 3, 4: the
+ * prologue and narrow forms of the ping-pong kernel), mi355_box_probe added.  102 (round 4): mi355_debug_config gained conv_pp and
  * conv_edge (carved out of its reserved tail: the struct's size is unchanged), attn_fused became a bit mask, mi355_unet_read_tensor
  * returns MI355_ERR_UNSUPPORTED for a tensor the plan did not materialise as stored.  Callers that fill a mi355_debug_config must start
  * from mi355_debug_defaults() (or zero the struct and set every field): a field this header does not know yet is then at its shipped
@@ -102,7 +105,7 @@ typedef struct mi355_unet_config {
   int32_t use_scale_shift_norm;
   int32_t resblock_updown;
   int32_t use_new_attention_order;
-  int32_t dtype; /* MI355_F32 | MI355_BF16 */
+  int32_t dtype; /* MI355_F32 | MI355_BF16 | MI355_BF16X2 */
   int32_t differentiable; /* 1: keep what mi355_unet_vjp needs (per-site GroupNorm statistics, the qkv tensors, transposed weights) */
   const mi355_debug_config* debug; /* NULL = defaults; copied at mi355_unet_create */
 } mi355_unet_config;
@@ -326,6 +329,15 @@ int mi355_rk_sqnorm(const float* a, const float* sub, const float* b, const floa
                     void* stream);
 int mi355_rk_interp(float* out, const float* y0, const float* y1, const float* y_mid, const float* f0, const float* f1, float dt, float x,
                     int64_t n, void* stream);
+
+/* ---- measurement: box calibration probe (bench.py roofline.box; no reference counterpart) ------------------------------------------
+ * A FROZEN kernel (csrc/box_probe.hip: 1.0995 TFLOP of bf16 v_mfma_f32_16x16x32 on seeded pseudo-random register operands, no memory
+ * traffic in its loop) that no round edits: boxes of the pool differ by several per cent for one build and the chip lowers its clock in
+ * MFMA-dense kernels, so throughput lines of different boxes / rounds are compared through this launch's duration.  Runs `reps` warm
+ * launches, then `reps` timed ones (HIP events on `stream`), synchronises; *us_per_launch = mean duration, *clock_mhz = median in-kernel
+ * clock of the last launch (s_memtime / s_memrealtime), *tflop = the work of one launch.  workspace: mi355_box_probe_workspace_bytes(). */
+int64_t mi355_box_probe_workspace_bytes(void);
+int mi355_box_probe(int reps, void* workspace, int64_t workspace_bytes, void* stream, float* us_per_launch, float* clock_mhz, float* tflop);
 
 /* Standalone conv / attention ops on NCHW fp32 tensors for parity tests of the HIP kernels
  * (pack -> implicit-GEMM MFMA kernel -> unpack; `workspace` from mi355_op_workspace_bytes). */

@@ -49,7 +49,7 @@ def _report(tag, got, ref):
 
 # ---- (a) cfg 2 at the bench batch ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x2"])
 def test_cfg2_b256_forward_and_euler_vs_oracle(precision):
     """BASELINE configs[1] at B = 256 (the measured configuration): every conv of the 32x32 and 16x16 levels takes
     conv3x3_ws_kernel here (two-source concat, RES_SAME residual, emb-initialised accumulators included) - compared with the CPU
@@ -64,6 +64,10 @@ def test_cfg2_b256_forward_and_euler_vs_oracle(precision):
     emax, scale, rms = _report(f"cfg2 B=256 forward {precision}", y[pick], ref)
     if precision == "fp32":
         torch.testing.assert_close(y[pick], ref, rtol=2e-4, atol=5e-5)
+    elif precision == "bf16x2":   # hi + lo weight halves: the activations' bf16 storage is left.  ONE forward barely shows it (random activation roundings of
+        # the same size as the weight roundings: measured max 0.94 % of scale, rms 0.70 % against 0.92 % / 0.84 % in bf16 mode); over a 50-step solve the
+        # weight error is the systematic one: per-sample rms of the final state 1.24e-3 against 4.94e-3 (profiles/r5_quality_delta_x2.json)
+        assert emax < 0.02 * scale and rms < 0.01
     else:
         assert emax < 0.04 * scale and rms < 0.02
     ts = torch.linspace(0, 1, 4)
@@ -74,6 +78,8 @@ def test_cfg2_b256_forward_and_euler_vs_oracle(precision):
     emax, scale, rms = _report(f"cfg2 B=256 3-step Euler {precision}", xg.cpu()[pick], xr)
     if precision == "fp32":
         torch.testing.assert_close(xg.cpu()[pick], xr, rtol=5e-4, atol=1e-4)
+    elif precision == "bf16x2":
+        assert emax < 0.02 * scale and rms < 0.005
     else:
         assert emax < 0.03 * scale and rms < 0.01
 
@@ -267,6 +273,70 @@ def test_pingpong_conv_prologue_and_narrow(case, dtype, rtol, atol):
     torch.testing.assert_close(outs[0], old, rtol=rtol, atol=atol)
 
 
+X2_CASES = [
+    # B, C0, C1, H, Cout, k, stride, resample, gn, emb, res_mode     MI355_BF16X2: weights as hi | lo bf16 halves along K, on every conv kernel family
+    (6, 256, 0, 16, 256, 3, 1, 0, False, True, 1),      # wide ping-pong
+    (40, 256, 256, 16, 256, 3, 1, 0, True, True, 0),    # wide ping-pong + prologue over a two-source concat: the chunk stream runs src0, src1, src0, src1
+    (5, 128, 0, 32, 128, 3, 1, 0, False, True, 1),      # narrow ping-pong
+    (64, 128, 128, 32, 128, 3, 1, 0, True, True, 1),    # warp-specialised kernel, prologue, concat
+    (256, 256, 0, 8, 256, 3, 1, 0, False, True, 1),     # small-level kernel 8x8
+    (255, 256, 256, 4, 256, 3, 1, 0, False, True, 1),   # small-level kernel 4x4, two phases
+    (9, 128, 0, 32, 128, 3, 2, 0, False, False, 0),     # stride 2: generic kernel
+    (3, 96, 0, 20, 64, 3, 1, 0, True, False, 0),        # generic kernel, odd sizes, prologue
+    (4, 3, 0, 32, 128, 3, 1, 0, False, False, 0),       # first conv (3 -> 128): the streaming kernel steps aside
+    (4, 128, 0, 32, 3, 3, 1, 0, True, False, 0),        # last conv (128 -> 3, NCHW fp32)
+    (40, 256, 256, 16, 256, 1, 1, 0, False, False, 1),  # 1x1 ping-pong (skip_connection over a concat)
+    (7, 256, 0, 8, 768, 1, 1, 0, True, False, 0),       # 1x1 qkv with the affine prologue on a small image
+    (9, 128, 0, 16, 256, 3, 1, 2, True, True, 0),       # nearest x2 gather + prologue
+]
+
+
+@pytest.mark.parametrize("case", X2_CASES)
+def test_conv_hi_lo_weight_split(case):
+    """MI355_BF16X2 (w = bf16(w) + bf16(w - bf16(w)), both halves against the same bf16 activations, fp32 accumulation) vs F.conv2d with fp32
+    weights (unet.py:559,719: the reference is fp32 end to end).  Without a prologue the activations are rounded to bf16 for the reference too, so
+    only the accumulation order and the 2^-17 weight residual remain (1e-3 of scale); with a prologue the normalised activation is rounded inside
+    the kernel, and per op that rounding (random, like the output's bf16 store) is as large as the weights': the error must not exceed plain bf16
+    mode's on the same input (the split pays over a trajectory, where the weight error is the systematic one: tools/quality_delta.py --x2)."""
+    from mi355.ops import default_ops as ops
+
+    B, C0, C1, H, Co, k, stride, resample, gn, use_emb, res_mode = case
+    seed = 9900 + hash(case) % 1000
+    x = (randn(seed, B, C0, H, H) * 1.3 + 0.1).bfloat16().float()
+    x1 = (randn(seed + 1, B, C1, H, H) * 0.7 - 0.2).bfloat16().float() if C1 else None
+    C = C0 + C1
+    sd = synth_state_dict({"in_layers.0.weight": (C,), "in_layers.0.bias": (C,), "weight": (Co, C, k, k), "bias": (Co,)}, seed + 2)
+    h = x if x1 is None else torch.cat((x, x1), dim=1)
+    if gn:
+        h = unet_ref.group_norm32(h, sd["in_layers.0.weight"], sd["in_layers.0.bias"])
+        if k == 3:
+            h = F.silu(h)
+    if resample == 2:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, sd["weight"], sd["bias"], stride=stride, padding=k // 2)
+    Ho = ref.shape[-1]
+    emb = randn(seed + 3, B, Co) * 0.5 if use_emb else None
+    res = (randn(seed + 4, B, Co, Ho, Ho)).bfloat16().float() if res_mode == 1 else None
+    if emb is not None:
+        ref = ref + emb[:, :, None, None]
+    if res is not None:
+        ref = ref + res
+    kw = dict(stride=stride, resample=resample, gn=(sd["in_layers.0.weight"].to(DEV), sd["in_layers.0.bias"].to(DEV)) if gn else None, gn_silu=gn and k == 3,
+              x1=x1.to(DEV) if x1 is not None else None, emb=emb.to(DEV) if emb is not None else None, res=res.to(DEV) if res is not None else None, res_mode=1)
+    got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], dtype=_lib.MI355_BF16X2, **kw).cpu()
+    scale = ref.abs().max().item()
+    e2 = (got - ref).abs().max().item()
+    nhwc = Co % 32 == 0            # NHWC outputs are stored as bf16 (2^-9 relative); the 3-channel output conv writes fp32
+    if not gn:
+        assert e2 < (6e-3 if nhwc else 1e-3) * scale, (e2, scale)
+    else:
+        got1 = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], dtype=_lib.MI355_BF16, **kw).cpu()
+        r1 = (got1 - ref).pow(2).mean().sqrt().item()
+        r2 = (got - ref).pow(2).mean().sqrt().item()
+        print(f"rms error bf16 {r1:.3e}  bf16x2 {r2:.3e}  (scale {scale:.2f})")
+        assert e2 < 2e-2 * scale and r2 < 1.02 * r1, (e2, r1, r2, scale)
+
+
 PP1_CASES = [
     # B, C0, C1, H, Cout, emb, res      prologue-free 1x1 convs with Cout % 256 == 0 on images of whole 256-pixel tiles => conv1x1_pp_kernel, forced
     (6, 256, 0, 16, 256, False, True),       # AttentionBlock proj_out: + x (unet.py:389,401), one tile per image
@@ -452,6 +522,8 @@ def test_cfg4_flowers64_b256_forward_and_euler_vs_oracle(precision):
     emax, scale, rms = _report(f"cfg4 B=256 2-step Euler {precision}", xg.cpu()[pick], xr)
     if precision == "fp32":
         torch.testing.assert_close(xg.cpu()[pick], xr, rtol=5e-4, atol=1e-4)
+    elif precision == "bf16x2":
+        assert emax < 0.02 * scale and rms < 0.005
     else:
         assert emax < 0.03 * scale and rms < 0.01
 

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--gain", default="auto", help="multiplier of out.2 (weight and bias); auto = 1 / rms of the field at t = 0")
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r3_quality_delta.json"))
     ap.add_argument("--split", action="store_true", help="round 4: which roundings carry the bf16 mode's error (see the module docstring)")
+    ap.add_argument("--x2", action="store_true", help="round 5: bf16 and bf16x2 (hi + lo weight halves) against fp32 mode, same x0: per-sample rms of the final state")
     a = ap.parse_args()
 
     import evaluation
@@ -103,6 +104,21 @@ def main():
 
     if a.split:
         return split(a, net, sd, dev, nb, gain, v_rms)
+    if a.x2:
+        x32, _ = sample_set("fp32", 0, a.nfe)
+        x16, _ = sample_set("bf16", 0, a.nfe)
+        xx2, _ = sample_set("bf16x2", 0, a.nfe)
+        x32m, _ = sample_set("fp32", 0, a.nfe - 1)
+        rms = lambda d: float(d.pow(2).mean().sqrt())
+        res = {"workload": "cifar10_cfm_euler50 (BASELINE configs[1] net, synthetic seeded weights)", "n_samples": int(x32.shape[0]), "nfe": a.nfe,
+               "field": {"out2_gain": gain, "rms_v_t0": v_rms},
+               "per_sample_rms_of_the_final_state_same_x0": {"bf16_vs_fp32": rms(x16 - x32), "bf16x2_vs_fp32": rms(xx2 - x32),
+                                                             f"scale: {a.nfe}_vs_{a.nfe - 1}_steps (fp32 mode)": rms(x32m - x32)},
+               "max_abs": {"bf16_vs_fp32": float((x16 - x32).abs().max()), "bf16x2_vs_fp32": float((xx2 - x32).abs().max())}}
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        json.dump(res, open(a.out, "w"), indent=1)
+        print(json.dumps(res))
+        return
     x16, u16 = sample_set("bf16", 0, a.nfe)
     x32, u32 = sample_set("fp32", 0, a.nfe)
     _, u32b = sample_set("fp32", 100000, a.nfe)          # disjoint x0: same-distribution floor
