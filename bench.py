@@ -43,7 +43,7 @@ import torch  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-BOX_REF_US = 600.0   # reference duration of the frozen box probe launch (csrc/box_probe.hip): lines are compared as value * launch_us / BOX_REF_US
+BOX_REF_US = 475.0   # reference duration of the frozen box probe launch (csrc/box_probe.hip): lines are compared as value * launch_us / BOX_REF_US
 
 CIFAR = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
              channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64)
@@ -339,7 +339,7 @@ def main():
     peak = PEAK_BF16_TFLOPS if a.precision in ("bf16", "bf16x2") else PEAK_F32_TFLOPS
     achieved = dfl / (dms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    for pmc_name in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
+    for pmc_name in ("r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
         pmc_file = os.path.join(REPO, "profiles", pmc_name)
         if os.path.exists(pmc_file) and a.precision == "bf16" and name == DEFAULT and B == 256:
             ent = json.load(open(pmc_file)).get("kernels", {}).get("conv3x3_ws_kernel")
