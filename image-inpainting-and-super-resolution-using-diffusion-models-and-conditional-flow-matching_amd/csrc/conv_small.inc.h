@@ -18,12 +18,16 @@ namespace sm {
 struct Args { int pwp, pimg, sh, plane, nphase, chp, red_bytes; };
 }  // namespace sm
 
-template <typename T, int KSPLIT, int NCHP, int PITU>
-__global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Args g) {
+// NI = 4: four waves of 64 output channels (one per SIMD).  NI = 2 (round 5, whole-chip launches of the 8x8 level): EIGHT waves of 32 channels, two per SIMD - the
+// same bytes through the CU's L1 path, but while one wave of a SIMD waits for its weight fragments the other multiplies (in-kernel stamps of the four-wave
+// form: weight stream alone 9.1 us, MFMAs alone 9.8 us, together 20: they added up instead of overlapping).
+template <typename T, int KSPLIT, int NCHP, int PITU, int NI = 4>
+__global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_small_kernel(ConvKArgs p, sm::Args g) {
   using E = Elem<T>;
   constexpr int CHUNK = E::CHUNK, ESZ = sizeof(T);
-  constexpr int NW = 4 / KSPLIT;          // waves along the output channels (64 each); KSPLIT waves share a channel block
-  constexpr int MI = 4, NI = 4, MPW = MI / KSPLIT;
+  constexpr int NW = (NI == 4 ? 4 : 8) / KSPLIT;   // waves along the output channels (16 NI each); KSPLIT waves share a channel block
+  constexpr int NT = NI == 4 ? 256 : 512;          // threads
+  constexpr int MI = 4, MPW = MI / KSPLIT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -31,7 +35,7 @@ __global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Arg
   const int kk = wave / NW, wn = wave - kk * NW;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.x * p.G;
-  const int co0 = ((int)blockIdx.y * NW + wn) * 64;
+  const int co0 = ((int)blockIdx.y * NW + wn) * (16 * NI);
   const int VWm = (1 << p.lvw) - 1, THm = (1 << p.lth) - 1;
 
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.bytes0, 0x00020000);
@@ -68,7 +72,7 @@ __global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Arg
     const float inv_ppi = 1.0f / (float)ppi, inv_pw = 1.0f / (float)p.PW;
 #pragma unroll
     for (int u = 0; u < PITU; ++u) {
-      const int i = tid + 256 * u, pp = i >> 2, q = i & 3;
+      const int i = tid + NT * u, pp = i >> 2, q = i & 3;
       int s = -1, dst = -1;
       if (pp < npv) {
         const int gi = (int)(((float)pp + 0.5f) * inv_ppi), r = pp - gi * ppi;
@@ -354,15 +358,15 @@ __global__ void __launch_bounds__(256) conv3x3_small_kernel(ConvKArgs p, sm::Arg
   auto warm_issue = [&]() {
     if (p.warm_bytes == 0) return;
     const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
-    const uint32_t rank = wg >> 3, per = (nwg + 7) >> 3, step = per * 256u * 128u;
-    uint32_t off = (rank * 256u + tid) * 128u;
+    const uint32_t rank = wg >> 3, per = (nwg + 7) >> 3, step = per * (uint32_t)NT * 128u;
+    uint32_t off = (rank * (uint32_t)NT + tid) * 128u;
     const char* base = reinterpret_cast<const char*>(p.warm);
 #pragma unroll
     for (int i = 0; i < 4; ++i, off += step) wv[i] = *reinterpret_cast<const uint32_t*>(base + (off < p.warm_bytes ? off : 0u));
   };
   if constexpr (W8) {                     // KSPLIT == 1: the wave's four pixel tiles are one image
     for_mine(final_issue);
-    float ls[NI] = {0.f, 0.f, 0.f, 0.f}, lq2[NI] = {0.f, 0.f, 0.f, 0.f};
+    float ls[NI] = {}, lq2[NI] = {};
     for_mine([&](auto mic) {
       constexpr int mi = decltype(mic)::value;
       f32x4 o[NI]; uint32_t ovo; int n;
@@ -449,20 +453,23 @@ int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* a
     if (!ok) { a.act_out = nullptr; a.warm = nullptr; a.warm_bytes = 0; }
     if (act_done) *act_done = ok ? 1 : 0;
   }
+  // whole-chip launches of the 8x8 level (one image per workgroup, no K split): eight waves of 32 channels (knob conv_small bit 1)
+  const bool w8x2 = w8 && ksplit == 1 && (enabled & 2) && a.Cout % 256 == 0;
   dim3 grid(tiles, a.Cout / (64 * nw));
   int rc = 0;
-  auto go = [&](auto kern) {
+  auto go = [&](auto kern, int threads) {
     rc = mi355_allow_big_lds(kern, "conv3x3 (small levels)");
-    if (rc == 0) hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, g);
+    if (rc == 0) hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, a, g);
   };
   if (w8) {
-    if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 16, 2>);
-    else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 16, 2>);
-    else go(conv3x3_small_kernel<T, 4, 16, 2>);
+    if (w8x2) go(conv3x3_small_kernel<T, 1, 16, 1, 2>, 512);
+    else if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 16, 2>, 256);
+    else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 16, 2>, 256);
+    else go(conv3x3_small_kernel<T, 4, 16, 2>, 256);
   } else {
-    if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 8, 3>);
-    else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 8, 3>);
-    else go(conv3x3_small_kernel<T, 4, 8, 3>);
+    if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 8, 3>, 256);
+    else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 8, 3>, 256);
+    else go(conv3x3_small_kernel<T, 4, 8, 3>, 256);
   }
   return rc;
 }
