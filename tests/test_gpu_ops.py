@@ -135,6 +135,15 @@ def test_first_conv_kernel(ops):
         old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], dtype=_lib.MI355_BF16, debug=_lib.debug_config(conv_edge=1)).cpu()
         torch.testing.assert_close(got, ref, rtol=3e-2, atol=3e-2)
         torch.testing.assert_close(got, old, rtol=1e-2, atol=1e-2)   # same bf16 operands, same bf16 output rounding: only the fp32 summation order differs
+        # tight check of the bf16-only kernel (no fp32 instantiation to hold to 5e-5): against fp32 math on the SAME bf16-rounded operands only the
+        # summation order and the final bf16 store remain - within one bf16 ulp of the value element by element, and zero-mean: a misplaced bias or
+        # tap of 1e-3 shows up in the per-channel mean error (random roundings average out over >= 512 pixels x B images)
+        xb, wb = x.bfloat16().float(), sd["weight"].bfloat16().float()
+        refb = F.conv2d(xb, wb, sd["bias"], padding=1)
+        err = got - refb
+        assert (err.abs() <= refb.abs() * 2.0 ** -7 + 2e-5).all(), float((err.abs() - refb.abs() * 2.0 ** -7).max())
+        bias_c = err.mean(dim=(0, 2, 3)).abs().max().item()
+        assert bias_c < 2e-4 * refb.abs().mean().item() + 2e-5, bias_c
 
 
 @pytest.mark.parametrize("dtype,tol", [(_lib.MI355_F32, 2e-5), (_lib.MI355_BF16, 2e-2)])

@@ -551,6 +551,11 @@ def _check_attention_block(run, shape, bound):
         print(f"{shape} lanes {lanes}: new-old {d / scale:.2e}, new-fp32 {err_new / scale:.2e}, old-fp32 {err_old / scale:.2e} (of the output rms)")
         assert d < 1.5 * err_old, (lanes, d, err_old, scale)        # two bf16 roundings of the same forward: as far apart as each is from fp32
         assert err_new < 1.15 * err_old + 1e-4 * scale, (lanes, err_new, err_old)
+        # the persistent kernel has no fp32 instantiation: a systematic error (a bias entering twice, a head's rows shifted) would hide inside the rms
+        # bounds above but not in the per-channel MEAN of the error over images x pixels, where the random bf16 roundings average out
+        b_new = (new - ref).mean(dim=(0, 2, 3)).abs().max().item()
+        b_old = (old - ref).mean(dim=(0, 2, 3)).abs().max().item()
+        assert b_new < 2.0 * b_old + 3e-4 * scale, (lanes, b_new, b_old, scale)
 
 
 @pytest.mark.gpu
