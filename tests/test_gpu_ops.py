@@ -143,7 +143,8 @@ def test_first_conv_kernel(ops):
         err = got - refb
         assert (err.abs() <= refb.abs() * 2.0 ** -7 + 2e-5).all(), float((err.abs() - refb.abs() * 2.0 ** -7).max())
         bias_c = err.mean(dim=(0, 2, 3)).abs().max().item()
-        assert bias_c < 2e-4 * refb.abs().mean().item() + 2e-5, bias_c
+        noise = 6.0 * err.std().item() / (B * H * W) ** 0.5        # 6 sigma of a per-channel mean of zero-mean rounding errors (max over 128 channels)
+        assert bias_c < noise + 1e-5, (bias_c, noise)
 
 
 @pytest.mark.parametrize("dtype,tol", [(_lib.MI355_F32, 2e-5), (_lib.MI355_BF16, 2e-2)])
