@@ -21,7 +21,7 @@ struct Args { int pwp, pimg, sh, plane, nphase, chp, red_bytes; };
 // NI = 4: four waves of 64 output channels (one per SIMD).  NI = 2 (round 5, whole-chip launches of the 8x8 level): EIGHT waves of 32 channels, two per SIMD - the
 // same bytes through the CU's L1 path, but while one wave of a SIMD waits for its weight fragments the other multiplies (in-kernel stamps of the four-wave
 // form: weight stream alone 9.1 us, MFMAs alone 9.8 us, together 20: they added up instead of overlapping).
-template <typename T, int KSPLIT, int NCHP, int PITU, int NI = 4>
+template <typename T, int KSPLIT, int NCHP, int PITU, int NI = 4, int W8_ = (NCHP == 16)>   // W8_: 8x8 output images (one per tile); else four 4x4 images
 __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_small_kernel(ConvKArgs p, sm::Args g) {
   using E = Elem<T>;
   constexpr int CHUNK = E::CHUNK, ESZ = sizeof(T);
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
     const int tx = m & VWm, ty = (m >> p.lvw) & THm, gi = m >> (p.lvw + p.lth);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int lin = gi * g.pimg + (ty + t / 3) * g.pwp + tx + t % 3;
+      const int lin = gi * g.pimg + (ty * p.stride + t / 3) * g.pwp + tx * p.stride + t % 3;
       aaddr[t][mi] = lin * 64 + 16 * (lq ^ ((lin >> g.sh) & 3));
     }
   }
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
   };
   // (arrays written and read under DIFFERENT runtime branches end up in scratch memory: with K-sharing waves a tile's loads and its
   // arithmetic stay inside one branch)
-  constexpr bool W8 = NCHP == 16;
+  constexpr bool W8 = W8_ != 0;
   constexpr bool ACT_OK = !(W8 && KSPLIT > 1);   // an 8x8 image split over K-sharing waves has no wave-local statistics (the host never asks)
   auto plain_tile = [&](auto mic) {
     f32x4 o[NI]; uint32_t ovo; int n;
@@ -412,13 +412,17 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
   }
 }
 
-// Shapes this kernel takes: 3x3, stride 1 (plain or nearest-x2 input), whole 8x8 / 4x4 output images, no GroupNorm prologue (these
+// Shapes this kernel takes: 3x3, whole 8x8 / 4x4 OUTPUT images, stride 1 (plain or nearest-x2 input) or - round 5 - stride 2 (the Downsample convs
+// 16 -> 8 and 8 -> 4, AD/image_diffusion/unet.py:217-240: the staged patch is the (2 Ho + 1)^2 input window, the fragment addresses step two
+// pixels per output pixel: 2-way bank conflicts on reads that are a tenth of this kernel's LDS budget), no GroupNorm prologue (these
 // levels normalise in a pass of their own), NHWC output with C_out % 128 == 0, residual at the output resolution or none.
 // 0 = launched, 1 = not eligible (the caller goes on to the plain kernel), < 0 = error
 template <typename T>
 int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* act_done) {
   ConvKArgs a = a0;
-  if (!enabled || ks != 3 || a.stride != 1 || a.out_mode != OUT_NHWC || a.pro_a) return 1;
+  if (!enabled || ks != 3 || a.out_mode != OUT_NHWC || a.pro_a) return 1;
+  const bool s2 = a.stride == 2;
+  if (s2 && (!(enabled & 4) || a.mode != CONV_STRIDE2 || a.Hc != 2 * a.Ho || a.Wc != 2 * a.Wo)) return 1;
   if (a.Ho != a.Wo || (a.Ho != 8 && a.Ho != 4) || a.Cout % 128 != 0) return 1;
   if (a.res_mode != RES_NONE && a.res_mode != RES_SAME) return 1;
   constexpr int CH = Elem<T>::CHUNK;
@@ -427,11 +431,11 @@ int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* a
   sm::Args g;
   a.lvw = a.lth = w8 ? 3 : 2;
   a.G = w8 ? 1 : 4;
-  a.PW = a.PH = a.Ho + 2;
-  g.pwp = w8 ? 16 : 8; g.sh = w8 ? 1 : 2;
+  a.PW = a.PH = s2 ? 2 * a.Ho + 1 : a.Ho + 2;
+  g.pwp = s2 ? a.PW : (w8 ? 16 : 8); g.sh = w8 ? 1 : 2;
   g.pimg = a.PH * g.pwp;
   g.plane = (a.G * g.pimg - (g.pwp - a.PW)) * 64;
-  const int nchp = w8 ? 16 : 8;
+  const int nchp = s2 ? (w8 ? 8 : 4) : (w8 ? 16 : 8);
   g.nphase = (a.nchunks + nchp - 1) / nchp;
   g.chp = a.nchunks / g.nphase;
   if (g.chp * g.nphase != a.nchunks) return 1;
@@ -454,14 +458,24 @@ int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* a
     if (act_done) *act_done = ok ? 1 : 0;
   }
   // whole-chip launches of the 8x8 level (one image per workgroup, no K split): eight waves of 32 channels (knob conv_small bit 1)
-  const bool w8x2 = w8 && ksplit == 1 && (enabled & 2) && a.Cout % 256 == 0;
+  const bool w8x2 = w8 && !s2 && ksplit == 1 && (enabled & 2) && a.Cout % 256 == 0;
   dim3 grid(tiles, a.Cout / (64 * nw));
   int rc = 0;
   auto go = [&](auto kern, int threads) {
     rc = mi355_allow_big_lds(kern, "conv3x3 (small levels)");
     if (rc == 0) hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, a, g);
   };
-  if (w8) {
+  if (s2) {   // (2 Ho + 1)^2 patch pixels per image: 289 x 4 / 256 -> 5 fragments per thread (8x8), 4 x 81 x 4 / 256 -> 6 (4x4)
+    if (w8) {
+      if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 8, 5, 4, 1>, 256);
+      else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 8, 5, 4, 1>, 256);
+      else go(conv3x3_small_kernel<T, 4, 8, 5, 4, 1>, 256);
+    } else {
+      if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 4, 6, 4, 0>, 256);
+      else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 4, 6, 4, 0>, 256);
+      else go(conv3x3_small_kernel<T, 4, 4, 6, 4, 0>, 256);
+    }
+  } else if (w8) {
     if (w8x2) go(conv3x3_small_kernel<T, 1, 16, 1, 2>, 512);
     else if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 16, 2>, 256);
     else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 16, 2>, 256);

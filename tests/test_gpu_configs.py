@@ -156,6 +156,38 @@ def test_ws_conv_concat_residual_emb(case, dtype, rtol, atol):
     torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
 
 
+S2_CASES = [
+    # B, Cin, H (input), Cout, emb       round 5: the stride-2 Downsample convs (unet.py:217-240) of the small levels on conv3x3_small_kernel
+    (256, 256, 16, 256, False),   # 16 -> 8 at the bench batch: one image per workgroup
+    (255, 256, 8, 256, True),     # 8 -> 4, odd batch (a tile with three images), K split over all four waves
+    (64, 128, 16, 256, False),    # fewer tiles than CUs: wave pairs split K
+    (30, 256, 16, 128, True),     # 128 output channels
+    (3, 512, 8, 256, False),      # tiny batch, two phases of four chunks
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+@pytest.mark.parametrize("dtype,rtol,atol", [(_lib.MI355_F32, 5e-5, 5e-5), (_lib.MI355_BF16, 3e-2, 3e-2)])
+def test_stride2_conv_on_small_level_kernel(case, dtype, rtol, atol):
+    """Downsample.op = conv_nd(dims, channels, out_channels, 3, stride=2, padding=1) (unet.py:227-229) at 16 -> 8 and 8 -> 4 through the small-level kernel
+    (conv_small bit 2) vs F.conv2d and vs the generic kernel it replaces."""
+    from mi355.ops import default_ops as ops
+
+    B, C, H, Co, use_emb = case
+    seed = 9700 + hash(case) % 1000
+    x = randn(seed, B, C, H, H) * 1.1 - 0.1
+    sd = synth_state_dict({"weight": (Co, C, 3, 3), "bias": (Co,)}, seed + 2)
+    emb = randn(seed + 3, B, Co) * 0.5 if use_emb else None
+    ref = F.conv2d(x, sd["weight"], sd["bias"], stride=2, padding=1)
+    if emb is not None:
+        ref = ref + emb[:, :, None, None]
+    kw = dict(stride=2, dtype=dtype, emb=emb.to(DEV) if emb is not None else None)
+    got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_small=7), **kw).cpu()
+    old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_small=3), **kw).cpu()
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
+    torch.testing.assert_close(got, old, rtol=rtol, atol=atol)
+
+
 PP_CASES = [
     # B, C0, C1, H, Cout, resample, emb, res_mode       prologue-free 3x3 convs with Cout % 256 == 0 => conv3x3_pp_kernel (conv_pp.inc.h), forced
     (6, 256, 0, 16, 256, 0, True, 1),        # ResBlock out_layers at 16x16 fed by an activated tensor: one tile per image, emb + residual
