@@ -7,7 +7,7 @@ One "step" = one pass of the hot path over one synthetic batch.  The default wor
 quantise and (N > 1) the single RCCL all-gather of the shards.  Inputs (x0, condition, weights) are resident in HBM
 before the timed region.  Weak scaling: every rank samples its own batch.
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--precision bf16|bf16x2|fp32]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--precision bf16|bf16x2|fp16|fp32]
     N > 1: either launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or plain
     `python bench.py --gpus N ...`: the parent then starts N fresh children of itself, one per GPU, with that environment (it has
     not touched the GPU at that point), relays rank 0's JSON line and exits with the worst child's code.
@@ -233,7 +233,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
     ap.add_argument("--nfe", type=int, default=0, help="network evaluations per sample (default: the workload's)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x2", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x2", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-out", default="", help="write the per-op HIP-event profile of one forward to this JSON file")
     ap.add_argument("--dry-run", action="store_true", help="launcher check: process group + shard ranges over gloo, no GPU call")
@@ -336,7 +336,7 @@ def main():
     fwd_ms = sum(r["ms"] for r in recs)
     cms, cfl = by["conv"]["ms"], by["conv"]["flops"]
     dms, dfl, dby = sum(r["ms"] for r in dom), sum(r["flops"] for r in dom), sum(r["bytes"] for r in dom)
-    peak = PEAK_BF16_TFLOPS if a.precision in ("bf16", "bf16x2") else PEAK_F32_TFLOPS
+    peak = PEAK_BF16_TFLOPS if a.precision in ("bf16", "bf16x2", "fp16") else PEAK_F32_TFLOPS
     achieved = dfl / (dms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     for pmc_name in ("r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)

@@ -199,10 +199,8 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
         u32x4 pfrag[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-          bf16x8 pb;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { pb[r] = (bf16)sacc[qb][2 * s2][r]; pb[4 + r] = (bf16)sacc[qb][2 * s2 + 1][r]; }
-          pfrag[qb] = __builtin_bit_cast(u32x4, pb);
+          const u32x2 p0 = pack4(sacc[qb][2 * s2], T()), p1 = pack4(sacc[qb][2 * s2 + 1], T());
+          pfrag[qb] = u32x4{p0[0], p0[1], p1[0], p1[1]};
         }
         // transposed read: lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of a 4-key x 16-channel block and
         // receives column (lane & 15) of its 4 rows = V^T[channel 16 ci + lr][4 consecutive keys]  (EXEC is all ones here)
@@ -251,10 +249,7 @@ __global__ void __launch_bounds__(256, (attn_min_blocks<T, CH, QB>())) attention
         if constexpr (!BF) {
           *reinterpret_cast<f32x4*>(dst) = f32x4{o[qb][ci][0] * inv, o[qb][ci][1] * inv, o[qb][ci][2] * inv, o[qb][ci][3] * inv};
         } else {
-          bf16x4 t;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[qb][ci][r] * inv);
-          *reinterpret_cast<bf16x4*>(dst) = t;
+          *reinterpret_cast<u32x2*>(dst) = pack4(f32x4{o[qb][ci][0] * inv, o[qb][ci][1] * inv, o[qb][ci][2] * inv, o[qb][ci][3] * inv}, T());
         }
       }
     }
@@ -300,7 +295,7 @@ int attention_launch(const AttnDesc& d, hipStream_t stream) {
   if (d.new_order) { a.qoff_h = d.ch; a.koff = a.C; a.voff = 2 * a.C; }
   else { a.qoff_h = 3 * d.ch; a.koff = d.ch; a.voff = 2 * d.ch; }
   a.scale2 = 1.0f / sqrtf((float)d.ch);
-  int rc = d.dtype == 0 ? launch_attn<float>(a, d.ch, stream) : launch_attn<bf16>(a, d.ch, stream);
+  int rc = dispatch_dtype(d.dtype, [&](auto t) { return launch_attn<decltype(t)>(a, d.ch, stream); });
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   return 0;

@@ -170,10 +170,8 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
 #pragma unroll
     for (int ks = 0; ks < KST; ++ks) {
       if constexpr (BF) {   // 32-channel k-step = tiles 2 ks and 2 ks + 1: elements 0-3 = channels 32 ks + 4 lq + r, 4-7 = + 16
-        bf16x8 t;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { t[r] = (bf16)acc[2 * ks][qb][r]; t[4 + r] = (bf16)acc[2 * ks + 1][qb][r]; }
-        qf[qb][ks] = __builtin_bit_cast(u32x4, t);
+        const u32x2 t0 = pack4(acc[2 * ks][qb], T()), t1 = pack4(acc[2 * ks + 1][qb], T());
+        qf[qb][ks] = u32x4{t0[0], t0[1], t1[0], t1[1]};
       } else {
         qf[qb][ks] = __builtin_bit_cast(u32x4, acc[ks][qb]);
       }
@@ -186,12 +184,9 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
     for (int ct = 0; ct < 4; ++ct) {
       const f32x4 kv = acc[4 + ct][qb], vv = acc[8 + ct][qb];
       if constexpr (BF) {
-        bf16x4 kt, vt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { kt[r] = (bf16)kv[r]; vt[r] = (bf16)vv[r]; }
         // K: the 16-byte slot (ks, lq) holds tile 2 ks (first 8 bytes) and tile 2 ks + 1 (last 8) = the q fragments' channel order
-        *reinterpret_cast<bf16x4*>(klds + tok * ROW + (ct >> 1) * 64 + lq * 16 + (ct & 1) * 8) = kt;
-        *reinterpret_cast<bf16x4*>(vlds + tok * ROW + (16 * ct + 4 * lq) * 2) = vt;   // V: natural [key][channel]
+        *reinterpret_cast<u32x2*>(klds + tok * ROW + (ct >> 1) * 64 + lq * 16 + (ct & 1) * 8) = pack4(kv, T());
+        *reinterpret_cast<u32x2*>(vlds + tok * ROW + (16 * ct + 4 * lq) * 2) = pack4(vv, T());   // V: natural [key][channel]
       } else {
         *reinterpret_cast<f32x4*>(klds + tok * ROW + ct * 64 + lq * 16) = kv;
         *reinterpret_cast<f32x4*>(vlds + tok * ROW + (16 * ct + 4 * lq) * 4) = vv;
@@ -262,10 +257,8 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
         u32x4 pfrag[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-          bf16x8 pb;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { pb[r] = (bf16)sacc[qb][2 * s2][r]; pb[4 + r] = (bf16)sacc[qb][2 * s2 + 1][r]; }
-          pfrag[qb] = __builtin_bit_cast(u32x4, pb);
+          const u32x2 p0 = pack4(sacc[qb][2 * s2], T()), p1 = pack4(sacc[qb][2 * s2 + 1], T());
+          pfrag[qb] = u32x4{p0[0], p0[1], p1[0], p1[1]};
         }
         const char* vrow = vb + (32 * s2 + 4 * lq + (lr >> 2)) * ROW + 8 * (lr & 3);
 #pragma unroll
@@ -304,10 +297,7 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
       if constexpr (!BF) {
         *reinterpret_cast<f32x4*>(dst) = f32x4{o[qb][ci][0] * inv, o[qb][ci][1] * inv, o[qb][ci][2] * inv, o[qb][ci][3] * inv};
       } else {
-        bf16x4 t;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[qb][ci][r] * inv);
-        *reinterpret_cast<bf16x4*>(dst) = t;
+        *reinterpret_cast<u32x2*>(dst) = pack4(f32x4{o[qb][ci][0] * inv, o[qb][ci][1] * inv, o[qb][ci][2] * inv, o[qb][ci][3] * inv}, T());
       }
     }
   }
@@ -324,9 +314,8 @@ __global__ void __launch_bounds__(512) attn_fused_kernel(AttnFuseArgs p) {
 #ifndef ATTN_ABLATE
 #define ATTN_ABLATE 0   // experiments only (make variant_src): compile-time ablation mask of the persistent kernel
 #endif
-template <int NCH>
+template <int NCH, typename T>   // T: bf16 or f16 (two-byte elements)
 __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, int lanes) {
-  using T = bf16;
   constexpr int V = 8, CHUNK = 32, CH = 64, QB = 2, TT = 256;
   constexpr int KST = 2, CI = 4;
   constexpr int ROW = CH * 2 + 32;
@@ -436,7 +425,7 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
     stamp(1);
     const char* wb0 = wlds + lr * 64 + 16 * (lq ^ ((lr >> 1) & 3));
     u32x4 qf[QB][KST];
-    bf16x4 kpk[QB][4], vpk[QB][4];
+    u32x2 kpk[QB][4], vpk[QB][4];
     auto rows_pass = [&](auto t0c, auto ntc, auto&& done) {
       constexpr int T0 = decltype(t0c)::value, NT = decltype(ntc)::value;
       __builtin_amdgcn_sched_barrier(0);     // the pass is one scheduling region: the groups below count ITS reads and MFMAs only
@@ -478,10 +467,9 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
-          bf16x8 t;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { t[r] = (bf16)(acc[2 * ks][qb][r] * c2); t[4 + r] = (bf16)(acc[2 * ks + 1][qb][r] * c2); }
-          qf[qb][ks] = __builtin_bit_cast(u32x4, t);
+          const f32x4 s0 = acc[2 * ks][qb], s1 = acc[2 * ks + 1][qb];
+          const u32x2 t0 = pack4(f32x4{s0[0] * c2, s0[1] * c2, s0[2] * c2, s0[3] * c2}, T()), t1 = pack4(f32x4{s1[0] * c2, s1[1] * c2, s1[2] * c2, s1[3] * c2}, T());
+          qf[qb][ks] = u32x4{t0[0], t0[1], t1[0], t1[1]};
         }
     });
     stamp(2);
@@ -490,8 +478,7 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) kpk[qb][ct][r] = (bf16)acc[ct][qb][r];
+          kpk[qb][ct] = pack4(acc[ct][qb], T());
     });
     stamp(3);
     rows_pass(IC3<8>(), IC3<4>(), [&](f32x4 (&acc)[4][QB]) {
@@ -499,8 +486,7 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) vpk[qb][ct][r] = (bf16)acc[ct][qb][r];
+          vpk[qb][ct] = pack4(acc[ct][qb], T());
     });
     stamp(4);
     if (more && tid < 2 * C) ablds[((it + 1) & 1) * 2 * C + tid] = abn;   // read two barriers later at the earliest
@@ -511,8 +497,8 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
           // K: the 16-byte slot (ks, lq) holds tile 2 ks (first 8 bytes) and tile 2 ks + 1 (last 8) = the q fragments' channel order
-          *reinterpret_cast<bf16x4*>(klds + key * ROW + (ct >> 1) * 64 + lq * 16 + (ct & 1) * 8) = kpk[qb][ct];
-          *reinterpret_cast<bf16x4*>(vlds + key * ROW + (16 * ct + 4 * lq) * 2) = vpk[qb][ct];   // V: natural [key][channel]
+          *reinterpret_cast<u32x2*>(klds + key * ROW + (ct >> 1) * 64 + lq * 16 + (ct & 1) * 8) = kpk[qb][ct];
+          *reinterpret_cast<u32x2*>(vlds + key * ROW + (16 * ct + 4 * lq) * 2) = vpk[qb][ct];   // V: natural [key][channel]
         }
       }
     };
@@ -591,10 +577,8 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
           u32x4 pfrag[QB];
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
-            bf16x8 pb;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { pb[r] = (bf16)sacc[qb][2 * s2][r]; pb[4 + r] = (bf16)sacc[qb][2 * s2 + 1][r]; }
-            pfrag[qb] = __builtin_bit_cast(u32x4, pb);
+            const u32x2 p0 = pack4(sacc[qb][2 * s2], T()), p1 = pack4(sacc[qb][2 * s2 + 1], T());
+            pfrag[qb] = u32x4{p0[0], p0[1], p1[0], p1[1]};
           }
           const char* vrow = vb + (32 * s2 + 4 * lq + (lr >> 2)) * ROW + 8 * (lr & 3);
 #pragma unroll
@@ -633,10 +617,7 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
       T* op = reinterpret_cast<T*>(p.out) + ((size_t)n * TT + tok0 + 16 * qb + lr) * C + h * CH;
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) {
-        bf16x4 t;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[qb][ci][r] * inv);
-        *reinterpret_cast<bf16x4*>(op + ci * 16 + 4 * lq) = t;
+        *reinterpret_cast<u32x2*>(op + ci * 16 + 4 * lq) = pack4(f32x4{o[qb][ci][0] * inv, o[qb][ci][1] * inv, o[qb][ci][2] * inv, o[qb][ci][3] * inv}, T());
       }
     }
     stamp(12);
@@ -649,9 +630,9 @@ __global__ void __launch_bounds__(512) attn_fused_pers_kernel(AttnFuseArgs p, in
   }
 }
 
-template <int NCH>
+template <int NCH, typename T>
 int launch_fused_pers(const AttnFuseArgs& a, int lanes, hipStream_t s) {
-  auto kern = attn_fused_pers_kernel<NCH>;
+  auto kern = attn_fused_pers_kernel<NCH, T>;
   constexpr size_t lds = (size_t)NCH * 192 * 64 + 2 * 128 * (64 * 2 + 32) + (size_t)4 * NCH * 32 * 4 + 192 * 4;
   static_assert(lds <= 160 * 1024, "persistent attention block: LDS budget");
   if (int rc = mi355_allow_big_lds(kern, "attention block (persistent)")) return rc;
@@ -699,16 +680,16 @@ int attn_fused_launch(const AttnFusedDesc& d, hipStream_t stream) {
   // that a workgroup visits more than one image (knob attn_fused: bit 1 = off, bits 8.. = image lanes override, tests only)
   const int knob = (d.knobs ? d.knobs : &mi355_default_debug())->attn_fused;
   int lanes = 0;
-  if (d.dtype == 1 && d.T == 256 && (d.C == 128 || d.C == 256) && !(knob & 2)) {
+  if (d.dtype != DT_F32 && d.T == 256 && (d.C == 128 || d.C == 256) && !(knob & 2)) {
     static const int cus = [] { int dev = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return n; }();
     lanes = std::max(8, cus / d.heads / 8 * 8);
     if (knob >> 8) lanes = knob >> 8;
     if (!(knob >> 8) && d.N < 2 * lanes) lanes = 0;   // fewer than two images per workgroup: nothing to amortise
     if (lanes > d.N) lanes = d.N;
   }
-  if (lanes > 0) rc = d.C == 256 ? launch_fused_pers<8>(a, lanes, stream) : launch_fused_pers<4>(a, lanes, stream);
-  else if (d.dtype == 0) rc = d.T == 256 ? launch_fused<float, 2>(a, stream) : launch_fused<float, 1>(a, stream);
-  else rc = d.T == 256 ? launch_fused<bf16, 2>(a, stream) : launch_fused<bf16, 1>(a, stream);
+  if (lanes > 0 && d.dtype == DT_F16) rc = d.C == 256 ? launch_fused_pers<8, f16>(a, lanes, stream) : launch_fused_pers<4, f16>(a, lanes, stream);
+  else if (lanes > 0) rc = d.C == 256 ? launch_fused_pers<8, bf16>(a, lanes, stream) : launch_fused_pers<4, bf16>(a, lanes, stream);
+  else rc = dispatch_dtype(d.dtype, [&](auto t) { using T = decltype(t); return d.T == 256 ? launch_fused<T, 2>(a, stream) : launch_fused<T, 1>(a, stream); });
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   return 0;

@@ -416,9 +416,9 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
                  int64_t workspace_bytes, void* stream) {
   const mi355_debug_config& K = debug ? *debug : mi355_default_debug();
   MI355_REQUIRE(x && w_host && y && workspace, -1, "conv2d: null argument");
-  MI355_REQUIRE(dtype == MI355_F32 || dtype == MI355_BF16 || dtype == MI355_BF16X2, -1, "conv2d: bad dtype");
+  MI355_REQUIRE(dtype == MI355_F32 || dtype == MI355_BF16 || dtype == MI355_BF16X2 || dtype == MI355_F16, -1, "conv2d: bad dtype");
   const int wsplit = dtype == MI355_BF16X2 ? 1 : 0;   // bf16 storage, weights as hi | lo bf16 halves along K
-  if (wsplit) dtype = MI355_BF16;
+  dtype = dtype == MI355_F16 ? DT_F16 : (wsplit ? DT_BF16 : dtype);   // the internal element-type code from here on (ops.h)
   MI355_REQUIRE(stride == 1 || stride == 2, -1, "conv2d: stride must be 1 or 2");
   MI355_REQUIRE(!(stride == 2 && resample), -1, "conv2d: stride 2 cannot be combined with resampling");
   MI355_REQUIRE((x1 != nullptr) == (cin1 > 0), -1, "conv2d: x1 and cin1 go together");
@@ -574,6 +574,8 @@ int mi355_qkv_attention(const float* qkv, float* out, int batch, int heads, int 
                         void* workspace, int64_t workspace_bytes, void* stream) {
   MI355_REQUIRE(qkv && out && workspace, -1, "qkv_attention: null argument");
   hipStream_t s = S(stream);
+  MI355_REQUIRE(dtype == MI355_F32 || dtype == MI355_BF16 || dtype == MI355_F16, -1, "qkv_attention: bad dtype");
+  dtype = dtype == MI355_F16 ? DT_F16 : dtype;
   const int esz = dtype == 0 ? 4 : 2, C = heads * head_channels;
   char* p = reinterpret_cast<char*>(workspace);
   void* qin = p; p += al256((size_t)batch * length * 3 * C * esz);

@@ -7,10 +7,14 @@
 #include <string>
 
 typedef __bf16 bf16;
+typedef _Float16 f16;      // MI355_F16 (round 5): fp16 storage + fp16 MFMA, the reference's own reduced-precision mode (use_fp16, unet.py:559)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -28,6 +32,29 @@ template <> struct Elem<bf16> {
   static constexpr int VEC = 8;
   static constexpr int DTYPE = 1;
 };
+template <> struct Elem<f16> {   // every layout decision follows the element SIZE (DTYPE 1 = two bytes): fp16 shares all of bf16's images
+  static constexpr int CHUNK = 32;
+  static constexpr int VEC = 8;
+  static constexpr int DTYPE = 1;
+};
+
+// Two-byte element helpers: the 32-bit word w holds elements (lo, hi) of consecutive channels.
+//   bf16: a shift / a mask (the value IS the upper half of an fp32); f16: v_cvt_f32_f16 (+ SDWA for the upper half)
+__device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi, bf16) {
+  lo = __builtin_bit_cast(float, w << 16); hi = __builtin_bit_cast(float, w & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi, f16) {
+  const f16x2 h = __builtin_bit_cast(f16x2, w);
+  lo = (float)h[0]; hi = (float)h[1];
+}
+__device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi, float) { lo = __builtin_bit_cast(float, w); hi = 0.f; }   // (never executed: fp32 images hold one element per word)
+typedef __bf16 bf16x2_c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16) { return __builtin_bit_cast(uint32_t, bf16x2_c{(bf16)lo, (bf16)hi}); }   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+__device__ __forceinline__ uint32_t pack2(float lo, float hi, f16) { return __builtin_bit_cast(uint32_t, f16x2{(f16)lo, (f16)hi}); }          // v_cvt_pk_f16_f32 .. (RNE; |x| > 65504 -> inf)
+__device__ __forceinline__ uint32_t pack2(float lo, float, float) { return __builtin_bit_cast(uint32_t, lo); }
+// four consecutive channels -> 8 bytes
+template <typename T> __device__ __forceinline__ u32x2 pack4(const float (&v)[4], T) { return u32x2{pack2(v[0], v[1], T()), pack2(v[2], v[3], T())}; }
+template <typename T> __device__ __forceinline__ u32x2 pack4(const f32x4& v, T) { return u32x2{pack2(v[0], v[1], T()), pack2(v[2], v[3], T())}; }
 
 // 16-B fragment <-> float conversions
 // NB: never __builtin_bit_cast a single element of an ext-vector lvalue (`bit_cast(float, v[i])` reads element 0
@@ -43,6 +70,10 @@ __device__ __forceinline__ void frag_to_float(const u32x4& v, float (&f)[8], bf1
     f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
   }
 }
+__device__ __forceinline__ void frag_to_float(const u32x4& v, float (&f)[8], f16) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unpack2(v[i], f[2 * i], f[2 * i + 1], f16());
+}
 __device__ __forceinline__ u32x4 float_to_frag(const float (&f)[4], float) {
   return __builtin_bit_cast(u32x4, f32x4{f[0], f[1], f[2], f[3]});
 }
@@ -52,12 +83,21 @@ __device__ __forceinline__ u32x4 float_to_frag(const float (&f)[8], bf16) {
   for (int i = 0; i < 8; ++i) b[i] = (bf16)f[i];  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
   return __builtin_bit_cast(u32x4, b);
 }
+__device__ __forceinline__ u32x4 float_to_frag(const float (&f)[8], f16) {
+  f16x8 b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b[i] = (f16)f[i];
+  return __builtin_bit_cast(u32x4, b);
+}
 
 // one 16-B x 16-B fragment pair -> 16x16 f32 accumulator.
 //   bf16: one v_mfma_f32_16x16x32_bf16 (K = 32 across the 4 lane quads)
 //   f32 : four v_mfma_f32_16x16x4_f32 (K = 16), exact f32 (k-ordered fmaf chain)
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, bf16) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, f16) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b, float) {
   const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);

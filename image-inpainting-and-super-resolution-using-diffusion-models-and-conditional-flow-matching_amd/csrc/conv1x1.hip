@@ -235,25 +235,22 @@ __global__ void __launch_bounds__(NT1, 2) conv1x1_kernel(K1Args p) {
               const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
-                ra[2 * j] = __builtin_bit_cast(float, xa[j] << 16); ra[2 * j + 1] = __builtin_bit_cast(float, xa[j] & 0xffff0000u);
-                rb[2 * j] = __builtin_bit_cast(float, xb[j] << 16); rb[2 * j + 1] = __builtin_bit_cast(float, xb[j] & 0xffff0000u);
+                unpack2(xa[j], ra[2 * j], ra[2 * j + 1], T());
+                unpack2(xb[j], rb[2 * j], rb[2 * j + 1], T());
               }
             }
-            bf16x4 ta, tb;
             float va[4], vb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               va[j] = acc[mi][2 * k][j] + ad[2 * k][j] + ra[j];
               vb[j] = acc[mi][2 * k + 1][j] + ad[2 * k + 1][j] + rb[j];
-              ta[j] = (bf16)va[j];
-              tb[j] = (bf16)vb[j];
             }
             if (do_gn) {
               const float vm = ovalid[mi] ? 1.f : 0.f;
               gp.add(2 * k, va[0], va[1], va[2], va[3], gn_mask, vm);
               gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], gn_mask, vm);
             }
-            const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+            const u32x2 pa2 = pack4(va, T()), pb2 = pack4(vb, T());
             const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
             const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, obase + k * PSTEP * ESZ, 0, 0);
@@ -337,17 +334,13 @@ int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used
   dim3 grid(mt, (ntiles + ntn - 1) / ntn);
   const size_t lds = (size_t)nchunks * BM * 64 + wl;
   int rc;
-  if (d.dtype == 0) {
-    if (BM == 128 && GC == 3) rc = launch1<float, 128, 3>(a, grid, lds, stream);
-    else if (BM == 128) rc = launch1<float, 128, 1>(a, grid, lds, stream);
-    else if (GC == 1) rc = launch1<float, 64, 1>(a, grid, lds, stream);
-    else rc = launch1<float, 64, 3>(a, grid, lds, stream);
-  } else {
-    if (BM == 128 && GC == 3) rc = launch1<bf16, 128, 3>(a, grid, lds, stream);
-    else if (BM == 128) rc = launch1<bf16, 128, 1>(a, grid, lds, stream);
-    else if (GC == 1) rc = launch1<bf16, 64, 1>(a, grid, lds, stream);
-    else rc = launch1<bf16, 64, 3>(a, grid, lds, stream);
-  }
+  rc = dispatch_dtype(d.dtype, [&](auto t) {
+    using T = decltype(t);
+    if (BM == 128 && GC == 3) return launch1<T, 128, 3>(a, grid, lds, stream);
+    if (BM == 128) return launch1<T, 128, 1>(a, grid, lds, stream);
+    if (GC == 1) return launch1<T, 64, 1>(a, grid, lds, stream);
+    return launch1<T, 64, 3>(a, grid, lds, stream);
+  });
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   if (gn_slots_used) *gn_slots_used = a.gn_slots;

@@ -31,20 +31,21 @@ struct OutArgs {
 // GN affine (+ SiLU) of one 16-byte fragment.  bf16: fp32 math on element PAIRS (v_pk_fma / v_pk_mul / v_pk_add_f32: two elements per VALU
 // issue; the pass is VALU-bound), the operation sequence of conv_ws.inc.h's ws_pro_frag.
 typedef __bf16 ebf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x4 edge_pro_frag(const u32x4& raw, const f32x2 (&a2)[4], const f32x2 (&b2)[4], bool silu, bf16) {
+template <typename T2>   // bf16 / f16
+__device__ __forceinline__ u32x4 edge_pro_frag(const u32x4& raw, const f32x2 (&a2)[4], const f32x2 (&b2)[4], bool silu, T2) {
   u32x4 out;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const uint32_t w = raw[i];
-    const f32x2 x = f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+    f32x2 x;
+    { float xl, xh; unpack2(w, xl, xh, T2()); x = f32x2{xl, xh}; }
     f32x2 v = a2[i] * x + b2[i];
     if (silu) {
       const f32x2 sc = v * f32x2{-1.4426950408889634f, -1.4426950408889634f};
       const f32x2 d = f32x2{__builtin_amdgcn_exp2f(sc[0]), __builtin_amdgcn_exp2f(sc[1])} + f32x2{1.0f, 1.0f};
       v = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     }
-    const ebf16x2 h = ebf16x2{(bf16)v[0], (bf16)v[1]};
-    out[i] = __builtin_bit_cast(uint32_t, h);
+    out[i] = pack2(v[0], v[1], T2());
   }
   return out;
 }
@@ -204,7 +205,7 @@ struct InArgs {
   int N, H, W, tiles_x, tiles_y;
 };
 
-template <bool GN>
+template <bool GN, typename T = bf16>   // T: bf16 or f16
 __global__ void __launch_bounds__(256, 4) conv3x3_in_kernel(InArgs p) {
   constexpr int NT = 8;                       // 16-channel tiles of the 128 output channels
   constexpr int PW = 18, NPX = PW * PW;       // haloed patch
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(256, 4) conv3x3_in_kernel(InArgs p) {
       for (int nt = 0; nt < NT; ++nt) {
         const u32x4 af = *reinterpret_cast<const u32x4*>(wl + wofs + (4 * ks * 128 + nt * 16) * 16);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) mma16(acc[mi][nt], af, bf[mi], bf16());
+        for (int mi = 0; mi < 2; ++mi) mma16(acc[mi][nt], af, bf[mi], T());
       }
     }
 #pragma unroll
@@ -284,10 +285,7 @@ __global__ void __launch_bounds__(256, 4) conv3x3_in_kernel(InArgs p) {
           gs[2 * k + 1] += (vb[0] + vb[1]) + (vb[2] + vb[3]);
           gq[2 * k + 1] = __builtin_fmaf(vb[0], vb[0], __builtin_fmaf(vb[1], vb[1], __builtin_fmaf(vb[2], vb[2], __builtin_fmaf(vb[3], vb[3], gq[2 * k + 1]))));
         }
-        bf16x4 ta, tb;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { ta[q] = (bf16)va[q]; tb[q] = (bf16)vb[q]; }
-        const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+        const u32x2 pa2 = pack4(va, T()), pb2 = pack4(vb, T());
         const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
         const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
         *reinterpret_cast<u32x4*>(op + k * 64) = u32x4{w0[0], w1[0], w0[1], w1[1]};
@@ -334,8 +332,7 @@ int conv_out_try_launch(const ConvDesc& d, hipStream_t stream) {
     return 0;
   };
   int rc;
-  if (d.dtype == 0) rc = fixed ? go(conv3x3_out_kernel<float, true>) : go(conv3x3_out_kernel<float, false>);
-  else rc = fixed ? go(conv3x3_out_kernel<bf16, true>) : go(conv3x3_out_kernel<bf16, false>);
+  rc = dispatch_dtype(d.dtype, [&](auto t) { using T = decltype(t); return fixed ? go(conv3x3_out_kernel<T, true>) : go(conv3x3_out_kernel<T, false>); });
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
@@ -345,7 +342,7 @@ int conv_out_try_launch(const ConvDesc& d, hipStream_t stream) {
 int conv_in_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
   if (!(K.conv_edge & 2) || d.wsplit) return 1;
-  if (d.dtype != 1 || d.ks != 3 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.src1 || d.res || d.emb || d.pro_a || d.act_out) return 1;
+  if (d.dtype == DT_F32 || d.ks != 3 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.src1 || d.res || d.emb || d.pro_a || d.act_out) return 1;
   if (d.cin_real < 1 || d.cin_real > 8 || d.C0 != 32 || d.Cout != 128 || conv_tile_n(d.Cout) != 128 || !d.bias) return 1;
   if (d.Hs % 16 != 0 || d.Ws % 16 != 0) return 1;
   InArgs a;
@@ -354,8 +351,10 @@ int conv_in_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used
   const int slots = a.tiles_x * a.tiles_y * 4;
   a.gn_stats = nullptr; a.gn_slots = 0;
   if (d.gn_stats && slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = slots; }
-  if (a.gn_stats) hipLaunchKernelGGL(conv3x3_in_kernel<true>, dim3(d.N * a.tiles_x * a.tiles_y), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(conv3x3_in_kernel<false>, dim3(d.N * a.tiles_x * a.tiles_y), dim3(256), 0, stream, a);
+  const dim3 gr(d.N * a.tiles_x * a.tiles_y);
+  if (d.dtype == DT_F16) { if (a.gn_stats) hipLaunchKernelGGL((conv3x3_in_kernel<true, f16>), gr, dim3(256), 0, stream, a); else hipLaunchKernelGGL((conv3x3_in_kernel<false, f16>), gr, dim3(256), 0, stream, a); }
+  else if (a.gn_stats) hipLaunchKernelGGL((conv3x3_in_kernel<true, bf16>), gr, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv3x3_in_kernel<false, bf16>), gr, dim3(256), 0, stream, a);
   MI355_CHECK_HIP(hipGetLastError());
   if (gn_slots_used) *gn_slots_used = a.gn_slots;
   return 0;

@@ -502,26 +502,23 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN / 2) conv_igemm_kernel(C
             const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              ra[2 * j] = __builtin_bit_cast(float, xa[j] << 16); ra[2 * j + 1] = __builtin_bit_cast(float, xa[j] & 0xffff0000u);
-              rb[2 * j] = __builtin_bit_cast(float, xb[j] << 16); rb[2 * j + 1] = __builtin_bit_cast(float, xb[j] & 0xffff0000u);
+              unpack2(xa[j], ra[2 * j], ra[2 * j + 1], T());
+              unpack2(xb[j], rb[2 * j], rb[2 * j + 1], T());
             }
           }
           const f32x4 ada = add4[MULTI ? mi : 0][2 * k], adb = add4[MULTI ? mi : 0][2 * k + 1];
-          bf16x4 ta, tb;
           float va[4], vb[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             va[j] = acc[mi][2 * k][j] + ada[j] + ra[j];
             vb[j] = acc[mi][2 * k + 1][j] + adb[j] + rb[j];
-            ta[j] = (bf16)va[j];
-            tb[j] = (bf16)vb[j];
           }
           if (do_gn) {
             const float vm = pvalid[mi] ? 1.f : 0.f;
             gp.add(2 * k, va[0], va[1], va[2], va[3], gn_mask, vm);
             gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], gn_mask, vm);
           }
-          const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+          const u32x2 pa2 = pack4(va, T()), pb2 = pack4(vb, T());
           const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
           const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
           __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo[mi] + k * PSTEP * ESZ, 0, 0);
@@ -696,7 +693,8 @@ void conv_pack_weights(int dtype, const float* w, int Cout, int Cin, int ks, voi
             if (lo) v = v - bf2f(f2bf(v));
             const int q = kl / V, e = kl % V;
             char* dstp = tile + row * 64 + 16 * (q ^ ((row >> 1) & 3)) + e * esz;
-            if (dtype == 0) memcpy(dstp, &v, 4);
+            if (dtype == DT_F32) memcpy(dstp, &v, 4);
+            else if (dtype == DT_F16) { const _Float16 h = (_Float16)v; memcpy(dstp, &h, 2); }   // RNE
             else { uint16_t h = f2bf(v); memcpy(dstp, &h, 2); }
           }
         }
@@ -764,7 +762,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
   MI355_REQUIRE(g.lds <= 160 * 1024, -4, "conv: LDS budget exceeded");
   MI355_REQUIRE(g.pit <= g.pit_t, -4, "conv: input patch too large for the staging loops");
   ConvKArgs a{};
-  MI355_REQUIRE(!d.wsplit || d.dtype == 1, -1, "conv: hi / lo split weights are a bf16 mode");
+  MI355_REQUIRE(!d.wsplit || d.dtype == DT_BF16, -1, "conv: hi / lo split weights are a bf16 mode");
   a.src0 = d.src0; a.src1 = d.src1; a.C0 = d.C0; a.C1 = d.C1; a.Cin = Cin; a.nreal = Cin / CH; a.nchunks = a.nreal * (d.wsplit ? 2 : 1);
   a.N = d.N; a.Hs = d.Hs; a.Ws = d.Ws; a.Hc = g.Hc; a.Wc = g.Wc; a.Ho = g.Ho; a.Wo = g.Wo;
   a.mode = d.mode; a.pad = g.pad; a.stride = g.stride;
@@ -802,7 +800,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
       a.act_out = d.act_out; a.act_gamma = d.act_gamma; a.act_beta = d.act_beta; a.act_film = d.act_film; a.act_film_stride = d.act_film_stride;
       a.act_eps = d.act_eps; a.act_silu = d.act_silu; a.act_raw = 0;
     }
-    const int r = d.dtype == 0 ? launch_pp<float>(a, K.conv_pp, d.ks, stream, &pp_act) : launch_pp<bf16>(a, K.conv_pp, d.ks, stream, &pp_act);
+    const int r = dispatch_dtype(d.dtype, [&](auto t) { return launch_pp<decltype(t)>(a, K.conv_pp, d.ks, stream, &pp_act); });
     if (r == 0) {
       MI355_CHECK_HIP(hipGetLastError());
       if (pp_act) { if (act_done) *act_done = 1; if (gn_slots_used) *gn_slots_used = 0; }
@@ -816,7 +814,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
   {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
     const int ws_slots = 2 * ((g.Wo + ws::VW - 1) / ws::VW) * ((g.Ho + ws::TH - 1) / ws::TH);   // (16x16 pixel tile, 8-row half) per image
     if (gn_ok && ws_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = ws_slots; }
-    const int r = d.dtype == 0 ? launch_ws<float>(a, K.conv_ws, g.BM, g.BN, d.ks, stream) : launch_ws<bf16>(a, K.conv_ws, g.BM, g.BN, d.ks, stream);
+    const int r = dispatch_dtype(d.dtype, [&](auto t) { return launch_ws<decltype(t)>(a, K.conv_ws, g.BM, g.BN, d.ks, stream); });
     if (r == 0) {
       MI355_CHECK_HIP(hipGetLastError());
       if (gn_slots_used) *gn_slots_used = a.gn_slots;
@@ -831,7 +829,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
       a.act_eps = d.act_eps; a.act_silu = d.act_silu; a.act_raw = d.act_raw;
       a.warm = (K.l2_warm & 1) ? d.warm : nullptr; a.warm_bytes = a.warm ? d.warm_bytes : 0u;
     }
-    const int r = d.dtype == 0 ? launch_small<float>(a, K.conv_small, d.ks, stream, act_done) : launch_small<bf16>(a, K.conv_small, d.ks, stream, act_done);
+    const int r = dispatch_dtype(d.dtype, [&](auto t) { return launch_small<decltype(t)>(a, K.conv_small, d.ks, stream, act_done); });
     if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
     if (act_done) *act_done = 0;
     a.act_out = nullptr; a.warm = nullptr; a.warm_bytes = 0;
@@ -841,8 +839,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
     const int slots = g.tiles_x * g.tiles_y * (g.BN == 32 ? 4 : 2);   // (pixel tile, pixel-wave) per image
     if (gn_ok && slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = slots; }
   }
-  int rc = d.dtype == 0 ? launch_cfg<float>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream)
-                        : launch_cfg<bf16>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream);
+  int rc = dispatch_dtype(d.dtype, [&](auto t) { return launch_cfg<decltype(t)>(a, g.BM, g.BN, d.ks, g.pit_t, grid, g.lds, stream); });
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   if (gn_slots_used) *gn_slots_used = a.gn_slots;

@@ -125,11 +125,11 @@ __device__ __forceinline__ void pp_barrier() {
 
 // silu(a x + b) of NV 32-bit words of a fragment (bf16: 2 NV channels, fp32: NV channels): the same operation sequence as the other conv kernels'
 // prologues, written stage by stage (the transcendental results are used a stage later: no dependent back-to-back issue)
-template <int NV>
-__device__ __forceinline__ void pp_pro_words(const uint32_t (&raw)[NV], const float* a, const float* b, uint32_t (&out)[NV], bf16) {
+template <int NV, typename T>
+__device__ __forceinline__ void pp_pro_words(const uint32_t (&raw)[NV], const float* a, const float* b, uint32_t (&out)[NV], T) {   // T = bf16 / f16
   float x[2 * NV], v[2 * NV], e[2 * NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { x[2 * i] = __builtin_bit_cast(float, raw[i] << 16); x[2 * i + 1] = __builtin_bit_cast(float, raw[i] & 0xffff0000u); }
+  for (int i = 0; i < NV; ++i) { unpack2(raw[i], x[2 * i], x[2 * i + 1], T()); }
 #pragma unroll
   for (int j = 0; j < 2 * NV; ++j) v[j] = a[j] * x[j] + b[j];
 #pragma unroll
@@ -142,9 +142,8 @@ __device__ __forceinline__ void pp_pro_words(const uint32_t (&raw)[NV], const fl
   for (int j = 0; j < 2 * NV; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
 #pragma unroll
   for (int j = 0; j < 2 * NV; ++j) v[j] = v[j] * e[j];
-  typedef __bf16 bf16x2_l __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int i = 0; i < NV; ++i) out[i] = __builtin_bit_cast(uint32_t, bf16x2_l{(bf16)v[2 * i], (bf16)v[2 * i + 1]});
+  for (int i = 0; i < NV; ++i) out[i] = pack2(v[2 * i], v[2 * i + 1], T());
 }
 template <int NV>
 __device__ __forceinline__ void pp_pro_words(const uint32_t (&raw)[NV], const float* a, const float* b, uint32_t (&out)[NV], float) {
@@ -543,24 +542,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(ConvKArgs p, int n_m
               const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
-                ra[2 * q] = __builtin_bit_cast(float, xa[q] << 16); ra[2 * q + 1] = __builtin_bit_cast(float, xa[q] & 0xffff0000u);
-                rb[2 * q] = __builtin_bit_cast(float, xb[q] << 16); rb[2 * q + 1] = __builtin_bit_cast(float, xb[q] & 0xffff0000u);
+                unpack2(xa[q], ra[2 * q], ra[2 * q + 1], T());
+                unpack2(xb[q], rb[2 * q], rb[2 * q + 1], T());
               }
             }
-            bf16x4 ta, tb;
             float va[4], vb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               va[q] = HAS_RES ? acc[mi][2 * k][q] + ra[q] : acc[mi][2 * k][q];
               vb[q] = HAS_RES ? acc[mi][2 * k + 1][q] + rb[q] : acc[mi][2 * k + 1][q];
-              ta[q] = (bf16)va[q];
-              tb[q] = (bf16)vb[q];
             }
             if constexpr (GNM != 0) {
               gp.add(2 * k, va[0], va[1], va[2], va[3], GNM == 2, vm[j]);
               gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], GNM == 2, vm[j]);
             }
-            const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+            const u32x2 pa2 = pack4(va, T()), pb2 = pack4(vb, T());
             const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
             const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo[j] + k * PSTEP * ESZ, 0, 0);
@@ -643,13 +639,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(ConvKArgs p, int n_m
         } else {
 #pragma unroll
           for (int k = 0; k < NP2; ++k) {
-            bf16x4 ta, tb;
+            float va[4], vb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              ta[q] = (bf16)actv(ga[2 * k][q] * acc[mi][2 * k][q] + gb[2 * k][q]);
-              tb[q] = (bf16)actv(ga[2 * k + 1][q] * acc[mi][2 * k + 1][q] + gb[2 * k + 1][q]);
+              va[q] = actv(ga[2 * k][q] * acc[mi][2 * k][q] + gb[2 * k][q]);
+              vb[q] = actv(ga[2 * k + 1][q] * acc[mi][2 * k + 1][q] + gb[2 * k + 1][q]);
             }
-            const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+            const u32x2 pa2 = pack4(va, T()), pb2 = pack4(vb, T());
             const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
             const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo + k * PSTEP * ESZ, 0, 0);

@@ -244,24 +244,21 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
               const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
-                ra[2 * q] = __builtin_bit_cast(float, xa[q] << 16); ra[2 * q + 1] = __builtin_bit_cast(float, xa[q] & 0xffff0000u);
-                rb[2 * q] = __builtin_bit_cast(float, xb[q] << 16); rb[2 * q + 1] = __builtin_bit_cast(float, xb[q] & 0xffff0000u);
+                unpack2(xa[q], ra[2 * q], ra[2 * q + 1], T());
+                unpack2(xb[q], rb[2 * q], rb[2 * q + 1], T());
               }
             }
-            bf16x4 ta, tb;
             float va[4], vb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               va[q] = HAS_RES ? acc[mi][2 * k][q] + ra[q] : acc[mi][2 * k][q];
               vb[q] = HAS_RES ? acc[mi][2 * k + 1][q] + rb[q] : acc[mi][2 * k + 1][q];
-              ta[q] = (bf16)va[q];
-              tb[q] = (bf16)vb[q];
             }
             if constexpr (GNM != 0) {
               gp.add(2 * k, va[0], va[1], va[2], va[3], false, 1.f);
               gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], false, 1.f);
             }
-            const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+            const u32x2 pa2 = pack4(va, T()), pb2 = pack4(vb, T());
             const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
             const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo[j] + k * PSTEP * ESZ, 0, 0);
@@ -325,8 +322,7 @@ static int pp1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_u
   const int slots = HW / 128;               // (pixel tile of the image, 128-pixel part)
   if (d.gn_stats && slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = slots; }
   int rc;
-  if (d.dtype == 0) rc = wide ? pp1_launch<float, 1>(a, n_mt, n_nt, stream) : pp1_launch<float, 0>(a, n_mt, n_nt, stream);
-  else rc = wide ? pp1_launch<bf16, 1>(a, n_mt, n_nt, stream) : pp1_launch<bf16, 0>(a, n_mt, n_nt, stream);
+  rc = dispatch_dtype(d.dtype, [&](auto t) { using T = decltype(t); return wide ? pp1_launch<T, 1>(a, n_mt, n_nt, stream) : pp1_launch<T, 0>(a, n_mt, n_nt, stream); });
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   if (gn_slots_used) *gn_slots_used = a.gn_slots;

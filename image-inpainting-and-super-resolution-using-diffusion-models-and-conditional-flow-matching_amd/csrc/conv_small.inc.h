@@ -254,8 +254,8 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
           const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            ra[2 * j] = __builtin_bit_cast(float, xa[j] << 16); ra[2 * j + 1] = __builtin_bit_cast(float, xa[j] & 0xffff0000u);
-            rb[2 * j] = __builtin_bit_cast(float, xb[j] << 16); rb[2 * j + 1] = __builtin_bit_cast(float, xb[j] & 0xffff0000u);
+            unpack2(xa[j], ra[2 * j], ra[2 * j + 1], T());
+            unpack2(xb[j], rb[2 * j], rb[2 * j + 1], T());
           }
         }
 #pragma unroll
@@ -273,10 +273,7 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
     } else {
 #pragma unroll
       for (int k = 0; k < NP2; ++k) {
-        bf16x4 ta, tb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ta[j] = (bf16)o[2 * k][j]; tb[j] = (bf16)o[2 * k + 1][j]; }
-        const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+        const u32x2 pa2 = pack4(o[2 * k], T()), pb2 = pack4(o[2 * k + 1], T());
         const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
         const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rs, ovo + k * PSTEP * ESZ, 0, 0);

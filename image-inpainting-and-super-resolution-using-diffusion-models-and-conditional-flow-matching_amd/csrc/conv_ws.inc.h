@@ -61,12 +61,14 @@ constexpr size_t LDS_BYTES = NPLANES * (size_t)PLANE + NWBUF * 3 * (size_t)WTILE
 // GN affine (+ SiLU) of one 16-byte fragment.  bf16: fp32 math on element PAIRS (v_pk_fma/mul/add_f32: two elements per VALU
 // issue; the loaders' VALU stream competes with the consumers' MFMA issue on the same SIMD, so every instruction counts).
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u32x4 ws_pro_frag(const u32x4& raw, const f32x2 (&a2)[4], const f32x2 (&b2)[4], bool silu, bf16) {
+template <typename T2>   // bf16 / f16
+__device__ __forceinline__ u32x4 ws_pro_frag(const u32x4& raw, const f32x2 (&a2)[4], const f32x2 (&b2)[4], bool silu, T2) {
   u32x4 out;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const uint32_t w = raw[i];
-    const f32x2 x = f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+    f32x2 x;
+    { float xl, xh; unpack2(w, xl, xh, T2()); x = f32x2{xl, xh}; }
     f32x2 v = a2[i] * x + b2[i];
     if (silu && (WS_ABLATE & 128)) {   // diagnostic only: same instruction count without the two transcendentals
       const f32x2 sc = v * f32x2{-1.4426950408889634f, -1.4426950408889634f};
@@ -77,8 +79,7 @@ __device__ __forceinline__ u32x4 ws_pro_frag(const u32x4& raw, const f32x2 (&a2)
       const f32x2 d = f32x2{__builtin_amdgcn_exp2f(sc[0]), __builtin_amdgcn_exp2f(sc[1])} + f32x2{1.0f, 1.0f};
       v = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     }
-    const bf16x2_t h = bf16x2_t{(bf16)v[0], (bf16)v[1]};
-    out[i] = __builtin_bit_cast(uint32_t, h);
+    out[i] = pack2(v[0], v[1], T2());
   }
   return out;
 }
@@ -853,24 +854,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(ConvKArgs p, int n_m
                 const uint32_t xa[2] = {s0[0], s1[0]}, xb[2] = {s0[1], s1[1]};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                  ra[2 * q] = __builtin_bit_cast(float, xa[q] << 16); ra[2 * q + 1] = __builtin_bit_cast(float, xa[q] & 0xffff0000u);
-                  rb[2 * q] = __builtin_bit_cast(float, xb[q] << 16); rb[2 * q + 1] = __builtin_bit_cast(float, xb[q] & 0xffff0000u);
+                  unpack2(xa[q], ra[2 * q], ra[2 * q + 1], T());
+                  unpack2(xb[q], rb[2 * q], rb[2 * q + 1], T());
                 }
               }
-              bf16x4 ta, tb;
               float va[4], vb[4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 va[q] = HAS_RES ? acc[mi][2 * k][q] + ra[q] : acc[mi][2 * k][q];
                 vb[q] = HAS_RES ? acc[mi][2 * k + 1][q] + rb[q] : acc[mi][2 * k + 1][q];
-                ta[q] = (bf16)va[q];
-                tb[q] = (bf16)vb[q];
               }
               if constexpr (GNM != 0) {
                 gp.add(2 * k, va[0], va[1], va[2], va[3], GNM == 2, vm[j]);
                 gp.add(2 * k + 1, vb[0], vb[1], vb[2], vb[3], GNM == 2, vm[j]);
               }
-              const u32x2 pa2 = __builtin_bit_cast(u32x2, ta), pb2 = __builtin_bit_cast(u32x2, tb);
+              const u32x2 pa2 = pack4(va, T()), pb2 = pack4(vb, T());
               const auto w0 = __builtin_amdgcn_permlane16_swap(pa2[0], pb2[0], false, false);
               const auto w1 = __builtin_amdgcn_permlane16_swap(pa2[1], pb2[1], false, false);
               __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rso, ovo[j] + k * PSTEP * ESZ, 0, 0);

@@ -195,16 +195,14 @@ int pack_nhwc_launch(int dtype, const float* x, int Cx, const float* cond, int C
   const int V = dtype == 0 ? 4 : 8;
   MI355_REQUIRE(Cpad % V == 0, -2, "pack_nhwc: padded channels must be whole 16-byte fragments");
   const size_t total = (size_t)N * HW * (Cpad / V);
-  if (dtype == 0) hipLaunchKernelGGL(pack_nhwc_kernel<float>, grid1d(total, 256), dim3(256), 0, s, x, Cx, cond, Cc, N, HW, Cpad, (float*)out);
-  else hipLaunchKernelGGL(pack_nhwc_kernel<bf16>, grid1d(total, 256), dim3(256), 0, s, x, Cx, cond, Cc, N, HW, Cpad, (bf16*)out);
+  dispatch_dtype(dtype, [&](auto t) { using T = decltype(t); hipLaunchKernelGGL(pack_nhwc_kernel<T>, grid1d(total, 256), dim3(256), 0, s, x, Cx, cond, Cc, N, HW, Cpad, (T*)out); return 0; });
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 int unpack_nchw_launch(int dtype, const void* in, int N, int HW, int C, float* out, hipStream_t s) {
   const size_t total = (size_t)N * HW * C;
-  if (dtype == 0) hipLaunchKernelGGL(unpack_nchw_kernel<float>, grid1d(total, 256), dim3(256), 0, s, (const float*)in, N, HW, C, out);
-  else hipLaunchKernelGGL(unpack_nchw_kernel<bf16>, grid1d(total, 256), dim3(256), 0, s, (const bf16*)in, N, HW, C, out);
+  dispatch_dtype(dtype, [&](auto t) { using T = decltype(t); hipLaunchKernelGGL(unpack_nchw_kernel<T>, grid1d(total, 256), dim3(256), 0, s, (const T*)in, N, HW, C, out); return 0; });
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -212,8 +210,7 @@ int unpack_nchw_launch(int dtype, const void* in, int N, int HW, int C, float* o
 int resample_launch(int dtype, const void* in, void* out, int N, int Hs, int Ws, int C, int mode, hipStream_t s) {
   const int Ho = mode == CONV_UP2 ? Hs * 2 : Hs / 2, Wo = mode == CONV_UP2 ? Ws * 2 : Ws / 2;
   const size_t total = (size_t)N * Ho * Wo * C;
-  if (dtype == 0) hipLaunchKernelGGL(resample_kernel<float>, grid1d(total, 256), dim3(256), 0, s, (const float*)in, (float*)out, N, Hs, Ws, C, mode);
-  else hipLaunchKernelGGL(resample_kernel<bf16>, grid1d(total, 256), dim3(256), 0, s, (const bf16*)in, (bf16*)out, N, Hs, Ws, C, mode);
+  dispatch_dtype(dtype, [&](auto t) { using T = decltype(t); hipLaunchKernelGGL(resample_kernel<T>, grid1d(total, 256), dim3(256), 0, s, (const T*)in, (T*)out, N, Hs, Ws, C, mode); return 0; });
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -343,8 +343,7 @@ int affine_pool_launch(int dtype, const void* in, const float* a, const float* b
   MI355_REQUIRE(C % V == 0 && Hs % 2 == 0 && Ws % 2 == 0, -2, "affine_pool: needs even size and 16-byte channel fragments");
   const size_t total = (size_t)N * (Hs / 2) * (Ws / 2) * (C / V);
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == 0) hipLaunchKernelGGL(affine_pool_kernel<float>, grid, dim3(256), 0, s, (const float*)in, a, b, silu, (float*)out, N, Hs, Ws, C);
-  else hipLaunchKernelGGL(affine_pool_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, a, b, silu, (bf16*)out, N, Hs, Ws, C);
+  dispatch_dtype(dtype, [&](auto t) { using T = decltype(t); hipLaunchKernelGGL(affine_pool_kernel<T>, grid, dim3(256), 0, s, (const T*)in, a, b, silu, (T*)out, N, Hs, Ws, C); return 0; });
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -367,13 +366,12 @@ int gn_affine_launch(const GnDesc& d, hipStream_t stream) {
     if (q == 1 || q == 2 || q == 4 || q == 8) nl = (int)q;
   }
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(d.N), dim3(nthreads), lds, stream, a); };
-  if (d.dtype == 0) {
-    switch (nl) { case 1: go(gn_affine_kernel<float, 1>); break; case 2: go(gn_affine_kernel<float, 2>); break; case 4: go(gn_affine_kernel<float, 4>); break;
-                  case 8: go(gn_affine_kernel<float, 8>); break; default: go(gn_affine_kernel<float, 0>); }
-  } else {
-    switch (nl) { case 1: go(gn_affine_kernel<bf16, 1>); break; case 2: go(gn_affine_kernel<bf16, 2>); break; case 4: go(gn_affine_kernel<bf16, 4>); break;
-                  case 8: go(gn_affine_kernel<bf16, 8>); break; default: go(gn_affine_kernel<bf16, 0>); }
-  }
+  dispatch_dtype(d.dtype, [&](auto t) {
+    using T = decltype(t);
+    switch (nl) { case 1: go(gn_affine_kernel<T, 1>); break; case 2: go(gn_affine_kernel<T, 2>); break; case 4: go(gn_affine_kernel<T, 4>); break;
+                  case 8: go(gn_affine_kernel<T, 8>); break; default: go(gn_affine_kernel<T, 0>); }
+    return 0;
+  });
   MI355_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -5,6 +5,16 @@
 
 const mi355_debug_config& mi355_default_debug();   // the shipped behaviour (capi.hip)
 
+// INTERNAL element-type codes of every descriptor below (the C ABI's MI355_* dtype values are translated at the boundary, capi.hip: MI355_BF16X2 ->
+// DT_BF16 + ConvDesc::wsplit, MI355_F16 -> DT_F16).  Sizes and chunking depend only on "4-byte or 2-byte": dtype == 0 ? 4 : 2.
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+// run f(T()) for the element type of an internal dtype code
+template <typename F> auto dispatch_dtype(int dtype, F&& f) {
+  if (dtype == DT_F32) return f(float());
+  if (dtype == DT_F16) return f(f16());
+  return f(bf16());
+}
+
 // ---- implicit-GEMM convolution -------------------------------------------------------------------
 // Activations are NHWC in HBM ([N][H][W][C], element type float or bf16).  out[n, y, x, co] =
 //   bias[co] + emb[n, co] + res[...] + sum_{tap, ci} W[co, ci, tap] * P(in)[n, y*s + ky - pad, x*s + kx - pad, ci]

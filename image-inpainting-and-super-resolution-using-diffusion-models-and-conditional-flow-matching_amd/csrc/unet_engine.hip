@@ -330,8 +330,9 @@ struct Walker {
 };
 
 int check_cfg(const mi355_unet_config& c) {
-  MI355_REQUIRE(c.dtype == MI355_F32 || c.dtype == MI355_BF16 || c.dtype == MI355_BF16X2, -1, "unet: dtype must be MI355_F32, MI355_BF16 or MI355_BF16X2");
-  MI355_REQUIRE(!(c.dtype == MI355_BF16X2 && c.differentiable), -4, "unet: the hi / lo weight split (MI355_BF16X2) has no backward pass");
+  MI355_REQUIRE(c.dtype == MI355_F32 || c.dtype == MI355_BF16 || c.dtype == MI355_BF16X2 || c.dtype == MI355_F16, -1,
+                "unet: dtype must be MI355_F32, MI355_BF16, MI355_BF16X2 or MI355_F16");
+  MI355_REQUIRE(!((c.dtype == MI355_BF16X2 || c.dtype == MI355_F16) && c.differentiable), -4, "unet: MI355_BF16X2 / MI355_F16 plans have no backward pass");
   MI355_REQUIRE(c.n_channel_mult >= 1 && c.n_channel_mult <= 8 && c.n_attention_ds >= 0 && c.n_attention_ds <= 8, -1, "unet: bad config arrays");
   MI355_REQUIRE(c.model_channels % 32 == 0 && c.model_channels > 0, -4, "unet: model_channels must be a multiple of 32 (GroupNorm32 + 64-byte channel chunks)");
   MI355_REQUIRE(c.in_channels > 0 && c.in_channels <= 32 && c.out_channels > 0 && c.out_channels <= 32, -4, "unet: in/out channels must be in 1..32");
@@ -412,8 +413,9 @@ int unet_enumerate_params(const mi355_unet_config& cfg, std::vector<ParamInfo>& 
 
 static int run_walker(const mi355_unet_config& cfg, const float* const* host, mi355_unet* net, Walker& w) {
   // MI355_BF16X2 = bf16 storage and MFMAs with every conv / qkv weight held as hi + lo bf16 halves: from here on the plan is a bf16 plan with wsplit set
+  // and MI355_F16 -> DT_F16: net->cfg.dtype holds the INTERNAL element-type code (ops.h) from here on
   net->wsplit = cfg.dtype == MI355_BF16X2 ? 1 : 0;
-  w.cfg = cfg; if (net->wsplit) w.cfg.dtype = MI355_BF16;
+  w.cfg = cfg; w.cfg.dtype = cfg.dtype == MI355_F16 ? DT_F16 : (net->wsplit ? DT_BF16 : cfg.dtype);
   w.dtype = w.cfg.dtype; w.esz = w.dtype == 0 ? 4 : 2; w.CH = w.dtype == 0 ? 16 : 32;
   w.dry = host == nullptr; w.host = host; w.net = net;
   if (int rc = unet_enumerate_params(cfg, w.params)) return rc;

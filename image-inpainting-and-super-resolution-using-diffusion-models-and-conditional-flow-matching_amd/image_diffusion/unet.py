@@ -147,7 +147,7 @@ class UNetModel(nn.Module):
         self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
         self.use_scale_shift_norm, self.resblock_updown = use_scale_shift_norm, resblock_updown
         self.use_new_attention_order = use_new_attention_order
-        self.precision = precision or ("bf16" if use_fp16 else DEFAULT_PRECISION)
+        self.precision = precision or ("fp16" if use_fp16 else DEFAULT_PRECISION)   # use_fp16: the reference runs its torso in float16 (unet.py:559-563)
         self._shapes = param_shapes(self)
         gen_bound = lambda fan_in: 1.0 / math.sqrt(fan_in)
         for name, shape in self._shapes.items():
@@ -179,7 +179,8 @@ class UNetModel(nn.Module):
     # ---- engine management -------------------------------------------------------------------
     def set_precision(self, precision: str):
         """'bf16' (bf16 storage + bf16 MFMA, fp32 accumulate / GN / softmax), 'bf16x2' (the same with every conv / qkv weight as hi + lo bf16
-        halves: no weight rounding, twice the MFMAs) or 'fp32' (exact f32 MFMA; the reference is fp32 end to end, unet.py:559,719)."""
+        halves: no weight rounding, twice the MFMAs), 'fp16' (fp16 storage + fp16 MFMA: the reference's use_fp16 mode, bf16's speed with three more
+        mantissa bits) or 'fp32' (exact f32 MFMA; the reference is fp32 end to end, unet.py:559,719)."""
         self.precision = precision
         self._engine = None
         self._dengine = None

@@ -16,6 +16,7 @@ CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 # a real file: the mapping in /proc/<pid>/maps then names a file of the repository's lib/ directory).  MI355_SAMPLER_LIB selects an experiment variant.
 LIB_PATH = os.environ.get("MI355_SAMPLER_LIB") or os.path.join(os.path.dirname(os.path.dirname(_HERE)), "lib", "libmi355_sampler.so")
 
+MI355_F16 = 3   # fp16 storage / MFMAs: the reference's own reduced-precision mode (use_fp16)
 MI355_F32, MI355_BF16, MI355_BF16X2 = 0, 1, 2   # BF16X2: bf16 storage / MFMAs, conv + qkv weights as hi + lo bf16 halves (weight rounding removed)
 DDPM_PRIOR, DDPM_AMORTIZED, DDPM_REPLACEMENT, DDIM = 0, 1, 2, 3
 

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import MI355BackendError, check
 
-_PREC = {"fp32": _lib.MI355_F32, "f32": _lib.MI355_F32, "bf16": _lib.MI355_BF16, "bf16x2": _lib.MI355_BF16X2}
+_PREC = {"fp32": _lib.MI355_F32, "f32": _lib.MI355_F32, "bf16": _lib.MI355_BF16, "bf16x2": _lib.MI355_BF16X2, "fp16": _lib.MI355_F16, "f16": _lib.MI355_F16}
 
 
 def param_inventory(cfg: _lib.UNetConfigC):

@@ -38,9 +38,12 @@ extern "C" {
 #define MI355_BF16X2 2 /* as MI355_BF16 with every conv / qkv weight held as two bf16 halves, hi = bf16(w) and lo = bf16(w - hi), multiplied by the
                         * same bf16 activations and accumulated in fp32 (twice the MFMAs): the weight rounding - 94 % of bf16 mode's distance to
                         * fp32 mode (profiles/r4_quality_delta.json) - is gone; mi355_unet_config::dtype and the test ops' dtype accept it */
+#define MI355_F16 3 /* fp16 storage + fp16 MFMA (v_mfma_f32_16x16x32_f16), fp32 accumulate; GN stats / softmax / x state fp32: the reference's own reduced-
+                     * precision mode (UNetModel(use_fp16=True) runs its torso in float16, AD/image_diffusion/unet.py:559-563): bf16's speed, three more
+                     * mantissa bits on every stored activation and weight; values beyond +-65504 overflow to inf as they do in the reference */
 
 /* ABI version = 100 * major + minor.  The minor number counts additive changes; 103 (round 5): conv_pp became a bit mask (bits 2, 3, 4: the
- * prologue and narrow forms of the ping-pong kernel), mi355_box_probe added.  102 (round 4): mi355_debug_config gained conv_pp and
+ * prologue and narrow forms of the ping-pong kernel), mi355_box_probe, MI355_BF16X2 and MI355_F16 added.  102 (round 4): mi355_debug_config gained conv_pp and
  * conv_edge (carved out of its reserved tail: the struct's size is unchanged), attn_fused became a bit mask, mi355_unet_read_tensor
  * returns MI355_ERR_UNSUPPORTED for a tensor the plan did not materialise as stored.  Callers that fill a mi355_debug_config must start
  * from mi355_debug_defaults() (or zero the struct and set every field): a field this header does not know yet is then at its shipped
@@ -106,7 +109,7 @@ typedef struct mi355_unet_config {
   int32_t use_scale_shift_norm;
   int32_t resblock_updown;
   int32_t use_new_attention_order;
-  int32_t dtype; /* MI355_F32 | MI355_BF16 | MI355_BF16X2 */
+  int32_t dtype; /* MI355_F32 | MI355_BF16 | MI355_BF16X2 | MI355_F16 */
   int32_t differentiable; /* 1: keep what mi355_unet_vjp needs (per-site GroupNorm statistics, the qkv tensors, transposed weights) */
   const mi355_debug_config* debug; /* NULL = defaults; copied at mi355_unet_create */
 } mi355_unet_config;

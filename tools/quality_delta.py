@@ -108,13 +108,14 @@ def main():
         x32, _ = sample_set("fp32", 0, a.nfe)
         x16, _ = sample_set("bf16", 0, a.nfe)
         xx2, _ = sample_set("bf16x2", 0, a.nfe)
+        xh, _ = sample_set("fp16", 0, a.nfe)
         x32m, _ = sample_set("fp32", 0, a.nfe - 1)
         rms = lambda d: float(d.pow(2).mean().sqrt())
         res = {"workload": "cifar10_cfm_euler50 (BASELINE configs[1] net, synthetic seeded weights)", "n_samples": int(x32.shape[0]), "nfe": a.nfe,
                "field": {"out2_gain": gain, "rms_v_t0": v_rms},
-               "per_sample_rms_of_the_final_state_same_x0": {"bf16_vs_fp32": rms(x16 - x32), "bf16x2_vs_fp32": rms(xx2 - x32),
+               "per_sample_rms_of_the_final_state_same_x0": {"bf16_vs_fp32": rms(x16 - x32), "bf16x2_vs_fp32": rms(xx2 - x32), "fp16_vs_fp32": rms(xh - x32),
                                                              f"scale: {a.nfe}_vs_{a.nfe - 1}_steps (fp32 mode)": rms(x32m - x32)},
-               "max_abs": {"bf16_vs_fp32": float((x16 - x32).abs().max()), "bf16x2_vs_fp32": float((xx2 - x32).abs().max())}}
+               "max_abs": {"bf16_vs_fp32": float((x16 - x32).abs().max()), "bf16x2_vs_fp32": float((xx2 - x32).abs().max()), "fp16_vs_fp32": float((xh - x32).abs().max())}}
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(res, open(a.out, "w"), indent=1)
         print(json.dumps(res))
