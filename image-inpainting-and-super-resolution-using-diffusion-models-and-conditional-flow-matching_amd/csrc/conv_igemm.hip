@@ -53,6 +53,8 @@ struct ConvKArgs {
   // only if somebody else reads it (act_raw); one touch of the NEXT conv's packed weights (the pass's L2 warm-up moves here too)
   void* act_out; const float* act_gamma; const float* act_beta; const float* act_film; int act_film_stride; float act_eps;
   int act_silu, act_raw;
+  int act_stride, act_coff, act_cpg; uint32_t abytes;   // act_out: channels per pixel, first channel this conv fills, channels per group, bytes
+  void* act2_out; const float* act2_gamma; const float* act2_beta; int act2_silu, act2_stride, act2_coff, act2_cpg; uint32_t a2bytes;   // a second site (no FiLM)
   const void* warm; uint32_t warm_bytes;
 };
 
@@ -827,12 +829,23 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
     if (d.act_out && act_done && (K.gn_epilogue & 1) && d.act_out != d.out) {
       a.act_out = d.act_out; a.act_gamma = d.act_gamma; a.act_beta = d.act_beta; a.act_film = d.act_film; a.act_film_stride = d.act_film_stride;
       a.act_eps = d.act_eps; a.act_silu = d.act_silu; a.act_raw = d.act_raw;
+      a.act_stride = d.act_stride ? d.act_stride : d.Cout; a.act_coff = d.act_coff; a.act_cpg = d.act_cpg ? d.act_cpg : d.Cout / 32;
+      const size_t ab = (size_t)d.N * g.Ho * g.Wo * a.act_stride * esz;
+      MI355_REQUIRE(ab < 0xFFFF0000ull, -4, "conv: activated output exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
+      a.abytes = (uint32_t)ab;
+      if (d.act2_out && (K.gn_epilogue & 4)) {
+        a.act2_out = d.act2_out; a.act2_gamma = d.act2_gamma; a.act2_beta = d.act2_beta; a.act2_silu = d.act2_silu;
+        a.act2_stride = d.act2_stride ? d.act2_stride : d.Cout; a.act2_coff = d.act2_coff; a.act2_cpg = d.act2_cpg ? d.act2_cpg : d.Cout / 32;
+        const size_t a2b = (size_t)d.N * g.Ho * g.Wo * a.act2_stride * esz;
+        MI355_REQUIRE(a2b < 0xFFFF0000ull, -4, "conv: activated output exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
+        a.a2bytes = (uint32_t)a2b;
+      }
       a.warm = (K.l2_warm & 1) ? d.warm : nullptr; a.warm_bytes = a.warm ? d.warm_bytes : 0u;
     }
     const int r = dispatch_dtype(d.dtype, [&](auto t) { return launch_small<decltype(t)>(a, K.conv_small, d.ks, stream, act_done); });
     if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
     if (act_done) *act_done = 0;
-    a.act_out = nullptr; a.warm = nullptr; a.warm_bytes = 0;
+    a.act_out = nullptr; a.act2_out = nullptr; a.warm = nullptr; a.warm_bytes = 0;
     if (r < 0) return r;
   }
   {

@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
   // final values of pixel tile mi (accumulator + bias + emb + residual), and where they go.  The loads (residual, emb) are issued for
   // every tile of the wave first (final_issue) and consumed afterwards (final_o): whatever is issued in between - the weight touches
   // of the fused-GroupNorm epilogue - then queues BEHIND them (a wave's loads return in order)
-  u32x4 rr_all[MI][NP2]; f32x4 ev_all[MI][NI]; uint32_t ovo_all[MI]; int n_all[MI];
+  u32x4 rr_all[MI][NP2]; f32x4 ev_all[MI][NI]; uint32_t opx_all[MI]; int n_all[MI];   // opx: output pixel index (one past the tensor's last for a pixel outside it: every offset built from it is out of range)
   auto final_issue = [&](auto mic) {
     constexpr int mi = decltype(mic)::value;
     const int m = mi * 16 + lr;
@@ -212,10 +212,9 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
     const int n = n0 + gi;
     n_all[mi] = n;
     const bool ok = n < p.N && ty < p.Ho && tx < p.Wo;
-    const uint32_t opix = (uint32_t)((n * p.Ho + ty) * p.Wo + tx);
-    const uint32_t ovo = ok ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.obytes;
-    ovo_all[mi] = ovo;
-    const uint32_t rvo = (ok && p.res_mode != RES_NONE) ? ovo : p.rbytes;
+    const uint32_t opix = ok ? (uint32_t)((n * p.Ho + ty) * p.Wo + tx) : (uint32_t)(p.N * p.Ho * p.Wo);
+    opx_all[mi] = opix;
+    const uint32_t rvo = (ok && p.res_mode != RES_NONE) ? (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ : p.rbytes;
     if (p.res_mode != RES_NONE) {
 #pragma unroll
       for (int k = 0; k < NP2; ++k) rr_all[mi][k] = buf_load16(rsr, rvo + k * PSTEP * ESZ, 0);
@@ -225,9 +224,9 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
       for (int ni = 0; ni < NI; ++ni) ev_all[mi][ni] = *reinterpret_cast<const f32x4*>(p.emb + (size_t)min(n, p.N - 1) * p.emb_stride + co_w + ni * 16);
     }
   };
-  auto final_o = [&](auto mic, f32x4 (&o)[NI], uint32_t& ovo, int& n) {
+  auto final_o = [&](auto mic, f32x4 (&o)[NI], uint32_t& opix, int& n) {
     constexpr int mi = decltype(mic)::value;
-    ovo = ovo_all[mi]; n = n_all[mi];
+    opix = opx_all[mi]; n = n_all[mi];
     const u32x4 (&rr)[NP2] = rr_all[mi];
     f32x4 ad[NI];
 #pragma unroll
@@ -293,9 +292,9 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
   constexpr bool W8 = W8_ != 0;
   constexpr bool ACT_OK = !(W8 && KSPLIT > 1);   // an 8x8 image split over K-sharing waves has no wave-local statistics (the host never asks)
   auto plain_tile = [&](auto mic) {
-    f32x4 o[NI]; uint32_t ovo; int n;
-    final_o(mic, o, ovo, n);
-    store_vals(o, rso, ovo);
+    f32x4 o[NI]; uint32_t opix; int n;
+    final_o(mic, o, opix, n);
+    store_vals(o, rso, (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ);
   };
   if (!ACT_OK || p.act_out == nullptr) {
     if constexpr (KSPLIT == 1) { for_mine(final_issue); for_mine(plain_tile); }
@@ -303,49 +302,73 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
     return;
   }
   if constexpr (ACT_OK) {
-  // ---- epilogue with the consumer's GroupNorm (+ SiLU) applied: GroupNorm32 (AD/image_diffusion/nn.py:11-13,87-94) over the conv's
+  // ---- epilogue with the consumers' GroupNorm (+ SiLU) applied: GroupNorm32 (AD/image_diffusion/nn.py:11-13,87-94) over the conv's
   // final values, fp32 statistics; a wave holds whole images (8x8: its four pixel tiles are one image; 4x4: pixel tile mi is image
-  // mi) x 64 channels = whole groups (cpg = 4 / 8 / 16: a lane's quad, two or four lq rows), so the statistics are wave-local:
-  // a DPP row sum over the 16 pixels of a tile row + one or two shuffles.  FiLM as in gn_affine_kernel. ----
+  // mi) x 64 (32) channels = whole groups (cpg = 4 / 8 / 16: a lane's quad, two or four lq rows), so the statistics are wave-local:
+  // a DPP row sum over the 16 pixels of a tile row + one or two shuffles.  FiLM as in gn_affine_kernel.  Up to two sites read the
+  // tensor (ops.h ConvDesc::act2_out): the row sums are shared, the group width, (gamma, beta) and destination are each site's own. ----
   constexpr bool FAST = E::DTYPE == 1;
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(p.act_out, 0, (p.ablate & 1) ? 0u : p.obytes, 0x00020000);
-  const int cpg = p.Cout >> 5;
-  const float inv_cnt = 1.0f / ((float)cpg * (float)(p.Ho * p.Wo));
-  f32x4 gam[NI], bet[NI];
+  struct ActSite { __amdgpu_buffer_rsrc_t rs; const float* gamma; const float* beta; const float* film; int film_stride, silu, stride, coff, cpg; float inv_cnt; };
+  const float npx = (float)(p.Ho * p.Wo);
+  const ActSite st1{__builtin_amdgcn_make_buffer_rsrc(p.act_out, 0, (p.ablate & 1) ? 0u : p.abytes, 0x00020000), p.act_gamma, p.act_beta, p.act_film,
+                    p.act_film_stride, p.act_silu, p.act_stride, p.act_coff, p.act_cpg, 1.0f / ((float)p.act_cpg * npx)};
+  const bool two = p.act2_out != nullptr;
+  const ActSite st2{__builtin_amdgcn_make_buffer_rsrc(two ? p.act2_out : p.act_out, 0, (two && !(p.ablate & 1)) ? p.a2bytes : 0u, 0x00020000), p.act2_gamma, p.act2_beta,
+                    nullptr, 0, p.act2_silu, p.act2_stride, p.act2_coff, two ? p.act2_cpg : 4, 1.0f / ((float)(two ? p.act2_cpg : 4) * npx)};
+  // Every parameter load of the epilogue is ISSUED before the weight touches below (a wave's loads return in order: a load issued behind the
+  // cold touches waits for HBM): (gamma, beta) of both sites here, FiLM (scale, shift) rows with the residual / emb loads of their tile.
+  f32x4 gam1[NI], bet1[NI], gam2[NI], bet2[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    gam[ni] = *reinterpret_cast<const f32x4*>(p.act_gamma + co_w + ni * 16);
-    bet[ni] = *reinterpret_cast<const f32x4*>(p.act_beta + co_w + ni * 16);
+    gam1[ni] = *reinterpret_cast<const f32x4*>(p.act_gamma + co_w + ni * 16);
+    bet1[ni] = *reinterpret_cast<const f32x4*>(p.act_beta + co_w + ni * 16);
+    gam2[ni] = *reinterpret_cast<const f32x4*>((two ? p.act2_gamma : p.act_gamma) + co_w + ni * 16);
+    bet2[ni] = *reinterpret_cast<const f32x4*>((two ? p.act2_beta : p.act_beta) + co_w + ni * 16);
   }
-  auto group_sum = [&](float v) {
-    v = GnPartial<1>::row_sum(v);
-    if (cpg >= 8) v += __shfl_xor(v, 16);
-    if (cpg >= 16) v += __shfl_xor(v, 32);
-    return v;
-  };
-  // y = silu?(a o + b) for pixel tile values o of image n, statistics (s, q) = group sums of o and o^2
-  auto apply_store = [&](const f32x4 (&o)[NI], const float (&gs)[NI], const float (&gq)[NI], int n, uint32_t ovo) {
-    f32x4 y[NI];
+  auto film_issue = [&](int n, f32x4 (&fsc)[NI], f32x4 (&fsh)[NI]) {
+    if (!p.act_film) return;
+    const float* fp = p.act_film + (size_t)min(n, p.N - 1) * p.act_film_stride + co_w;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const float mean = gs[ni] * inv_cnt;
-      const float var = fmaxf(gq[ni] * inv_cnt - mean * mean, 0.f);
+      fsc[ni] = *reinterpret_cast<const f32x4*>(fp + ni * 16);
+      fsh[ni] = *reinterpret_cast<const f32x4*>(fp + p.Cout + ni * 16);
+    }
+  };
+  // (a, b) of one image's channels co_w + 16 ni + j for one site, from the row sums (rs, rq) of the values and their squares
+  auto site_ab = [&](const ActSite& st, const f32x4 (&gam)[NI], const f32x4 (&bet)[NI], const f32x4 (&fsc)[NI], const f32x4 (&fsh)[NI],
+                     const float (&rs)[NI], const float (&rq)[NI], f32x4 (&A)[NI], f32x4 (&Bv)[NI]) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float gs = rs[ni], gq = rq[ni];
+      if (st.cpg >= 8) { gs += __shfl_xor(gs, 16); gq += __shfl_xor(gq, 16); }
+      if (st.cpg >= 16) { gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32); }
+      const float mean = gs * st.inv_cnt;
+      const float var = fmaxf(gq * st.inv_cnt - mean * mean, 0.f);
       const float rstd = 1.0f / sqrtf(var + p.act_eps);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float a = rstd * gam[ni][j];
         float b = bet[ni][j] - mean * a;
-        if (p.act_film) {
-          const float* fp = p.act_film + (size_t)min(n, p.N - 1) * p.act_film_stride + co_w + ni * 16 + j;
-          const float sc = 1.0f + fp[0], sh = fp[p.Cout];
+        if (st.film) {
+          const float sc = 1.0f + fsc[ni][j];
           a *= sc;
-          b = b * sc + sh;
+          b = b * sc + fsh[ni][j];
         }
-        const float v = a * o[ni][j] + b;
-        y[ni][j] = p.act_silu ? (FAST ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)) : v / (1.0f + expf(-v))) : v;
+        A[ni][j] = a; Bv[ni][j] = b;
       }
     }
-    store_vals(y, rsa, ovo);
+  };
+  // y = silu?(a o + b) of pixel tile values o, to the site's tensor
+  auto apply_store = [&](const ActSite& st, const f32x4 (&o)[NI], const f32x4 (&A)[NI], const f32x4 (&Bv)[NI], uint32_t opix) {
+    f32x4 y[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = A[ni][j] * o[ni][j] + Bv[ni][j];
+        y[ni][j] = st.silu ? (FAST ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)) : v / (1.0f + expf(-v))) : v;
+      }
+    store_vals(y, st.rs, (opix * (uint32_t)st.stride + (uint32_t)(st.coff + co_s)) * ESZ);
   };
   // Touch of the NEXT conv's packed weights (the pass that used to warm the L2s with them is gone; as common.h l2_warm_wave, spread
   // over all waves: the workgroups of an XCD cover the range once).  A wave's loads return in order, so the cold touches go behind
@@ -363,12 +386,14 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
   };
   if constexpr (W8) {                     // KSPLIT == 1: the wave's four pixel tiles are one image
     for_mine(final_issue);
+    f32x4 fsc[NI] = {}, fsh[NI] = {};
+    film_issue(n0, fsc, fsh);
     float ls[NI] = {}, lq2[NI] = {};
     for_mine([&](auto mic) {
       constexpr int mi = decltype(mic)::value;
-      f32x4 o[NI]; uint32_t ovo; int n;
-      final_o(mic, o, ovo, n);
-      if (p.act_raw) store_vals(o, rso, ovo);
+      f32x4 o[NI]; uint32_t opix; int n;
+      final_o(mic, o, opix, n);
+      if (p.act_raw) store_vals(o, rso, (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         acc[mi][ni] = o[ni];
@@ -377,32 +402,50 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
       }
     });
     warm_issue();
-    float gs[NI], gq[NI];
+    float rs[NI], rq[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) { gs[ni] = group_sum(ls[ni]); gq[ni] = group_sum(lq2[ni]); }
-    for_mine([&](auto mic) {
-      constexpr int mi = decltype(mic)::value;
-      apply_store(acc[mi], gs, gq, n_all[mi], ovo_all[mi]);
-    });
+    for (int ni = 0; ni < NI; ++ni) { rs[ni] = GnPartial<1>::row_sum(ls[ni]); rq[ni] = GnPartial<1>::row_sum(lq2[ni]); }
+    auto one_site = [&](const ActSite& st, const f32x4 (&gam)[NI], const f32x4 (&bet)[NI]) {
+      f32x4 A[NI], Bv[NI];
+      site_ab(st, gam, bet, fsc, fsh, rs, rq, A, Bv);
+      for_mine([&](auto mic) {
+        constexpr int mi = decltype(mic)::value;
+        apply_store(st, acc[mi], A, Bv, opx_all[mi]);
+      });
+    };
+    one_site(st1, gam1, bet1);
+    if (two) one_site(st2, gam2, bet2);
   } else {                                // pixel tile mi is image mi
     bool warmed = false;
+    f32x4 fsc_all[MI][NI] = {}, fsh_all[MI][NI] = {};
+    auto film_tile = [&](auto mic) {
+      constexpr int mi = decltype(mic)::value;
+      film_issue(n_all[mi], fsc_all[mi], fsh_all[mi]);
+    };
     auto act_tile = [&](auto mic) {
-      f32x4 o[NI]; uint32_t ovo; int n;
-      final_o(mic, o, ovo, n);
-      if (p.act_raw) store_vals(o, rso, ovo);
+      constexpr int mi = decltype(mic)::value;
+      f32x4 o[NI]; uint32_t opix; int n;
+      final_o(mic, o, opix, n);
+      if (p.act_raw) store_vals(o, rso, (opix * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ);
       if (!warmed) { warm_issue(); warmed = true; }
-      float gs[NI], gq[NI];
+      float rs[NI], rq[NI];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1 += o[ni][j]; s2 += o[ni][j] * o[ni][j]; }
-        gs[ni] = group_sum(s1); gq[ni] = group_sum(s2);
+        rs[ni] = GnPartial<1>::row_sum(s1); rq[ni] = GnPartial<1>::row_sum(s2);
       }
-      apply_store(o, gs, gq, n, ovo);
+      f32x4 A[NI], Bv[NI];
+      site_ab(st1, gam1, bet1, fsc_all[mi], fsh_all[mi], rs, rq, A, Bv);
+      apply_store(st1, o, A, Bv, opix);
+      if (two) {
+        site_ab(st2, gam2, bet2, fsc_all[mi], fsh_all[mi], rs, rq, A, Bv);
+        apply_store(st2, o, A, Bv, opix);
+      }
     };
-    if constexpr (KSPLIT == 1) { for_mine(final_issue); for_mine(act_tile); }
-    else for_mine([&](auto mic) { final_issue(mic); act_tile(mic); });
+    if constexpr (KSPLIT == 1) { for_mine(final_issue); for_mine(film_tile); for_mine(act_tile); }
+    else for_mine([&](auto mic) { final_issue(mic); film_tile(mic); act_tile(mic); });
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wv[i]));   // the touches have landed before the wave ends
@@ -449,10 +492,12 @@ int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* a
   if (lds > 160 * 1024) return 1;
   a.gn_stats = nullptr; a.gn_slots = 0;
   {   // GroupNorm of the output in the epilogue: whole images per wave (an 8x8 image split over K-sharing waves is not), 4 / 8 / 16 channels per group
-    const int cpg = a.Cout / 32;
-    const bool ok = a.act_out && a.Cout % 32 == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && (!w8 || ksplit == 1);
+    auto cpg_ok = [&](int cpg, int coff) { return (cpg == 4 || cpg == 8 || cpg == 16) && a.Cout % cpg == 0 && coff % cpg == 0; };
+    const bool ok = a.act_out && cpg_ok(a.act_cpg, a.act_coff) && (!w8 || ksplit == 1);
     if (!ok) { a.act_out = nullptr; a.warm = nullptr; a.warm_bytes = 0; }
-    if (act_done) *act_done = ok ? 1 : 0;
+    const bool ok2 = ok && a.act2_out && cpg_ok(a.act2_cpg, a.act2_coff);
+    if (!ok2) a.act2_out = nullptr;
+    if (act_done) *act_done = (ok ? 1 : 0) | (ok2 ? 2 : 0);
   }
   // whole-chip launches of the 8x8 level (one image per workgroup, no K split): eight waves of 32 channels (knob conv_small bit 1)
   const bool w8x2 = w8 && !s2 && ksplit == 1 && (enabled & 2) && a.Cout % 256 == 0;

@@ -53,6 +53,14 @@ struct ConvDesc {
   // of the next conv's packed weights (warm).  conv_launch reports through *act_done whether the launch did it (0: run the pass).
   void* act_out = nullptr; const float* act_gamma = nullptr; const float* act_beta = nullptr;
   const float* act_film = nullptr; int act_film_stride = 0; float act_eps = 1e-5f; int act_silu = 0, act_raw = 1;
+  // Where the site is the GroupNorm of a CONCAT consumer (unet.py:650: h = cat([h, hs.pop()])) and its groups are whole inside each
+  // source, this conv's output is one source of it: act_out then has act_stride channels per pixel (0 = Cout) of which this conv fills
+  // act_coff ..., in groups of act_cpg channels (0 = Cout / 32); act_gamma / act_beta already point at channel act_coff.
+  int act_stride = 0, act_coff = 0, act_cpg = 0;
+  // A skip connection is read by TWO such sites (the next ResBlock's in_layers norm now, the up path's concat norm later): the second
+  // one, same conventions, never FiLM.  *act_done: bit 0 = the first site was applied, bit 1 = the second.
+  void* act2_out = nullptr; const float* act2_gamma = nullptr; const float* act2_beta = nullptr;
+  int act2_silu = 0, act2_stride = 0, act2_coff = 0, act2_cpg = 0;
   const void* warm = nullptr; uint32_t warm_bytes = 0;
   int cin_real = 0;                         // > 0: only the first cin_real channels of src0 are non-zero (the network's first conv: in_channels padded to a chunk)
   int wsplit = 0;                           // 1 (bf16x2 precision): w holds [bf16(w) | bf16(w - bf16(w))] along K (twice the chunks): the contraction runs over the

@@ -538,10 +538,18 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   std::vector<char> gn_done(net->ops.size(), 0);
   std::vector<char> pro_off(net->ops.size(), 0);   // convs whose input arrives already normalised (16x16 level: applied IN PLACE by the producer)
   std::vector<int> readers(net->tensors.size(), 0);
-  for (const PlanOp& o : net->ops) {
+  // apply-type GroupNorm sites (small images) by the tensors they read, and how many of a site's sources their producers have already applied
+  std::vector<std::vector<int>> apply_sites(net->tensors.size());
+  std::vector<char> site_parts(net->ops.size(), 0);
+  for (size_t j = 0; j < net->ops.size(); ++j) {
+    const PlanOp& o = net->ops[j];
     if (o.src0 >= 0) ++readers[o.src0];
     if (o.src1 >= 0) ++readers[o.src1];
     if (o.kind == OP_CONV && o.res >= 0) ++readers[o.res];
+    if (o.kind == OP_GN && o.dst >= 0 && o.gn_site < 0) {
+      apply_sites[o.src0].push_back((int)j);
+      if (o.src1 >= 0) apply_sites[o.src1].push_back((int)j);
+    }
   }
   int rc;
   auto mark = [&](const mi355_op_profile& r) {
@@ -636,18 +644,47 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
           }
         }
       }
-      if (!try_act && op.dst >= 0 && op.out_mode == OUT_NHWC && oi + 1 < net->ops.size()) {
-        const PlanOp& g = net->ops[oi + 1];   // the apply-type GroupNorm site (small images) that reads this conv's output and nothing else
-        if (g.kind == OP_GN && g.dst >= 0 && g.src0 == op.dst && g.src1 < 0 && g.gn_site < 0) {
-          c.act_out = TP(g.dst); c.act_gamma = WF(g.gamma_off); c.act_beta = WF(g.beta_off);
-          if (g.film_emb_off >= 0) { c.act_film = embp + g.film_emb_off; c.act_film_stride = estride; }
-          c.act_silu = g.pro_silu; c.act_raw = readers[op.dst] > 1;
-          warm_next(g, c.warm, c.warm_bytes, 1);
+      int fused_site[2] = {-1, -1};
+      if (!try_act && op.dst >= 0 && op.out_mode == OUT_NHWC) {
+        // The apply-type GroupNorm sites (small images) that read this conv's output: the one that follows it (in_layers / out_layers norm of
+        // the next conv, unet.py:196-212) and, for a skip connection, the norm of the up path's concat (unet.py:650), whose groups are whole
+        // inside each source when both channel counts are multiples of the group width: each producer then applies its own channels.
+        for (int gi : apply_sites[op.dst]) {
+          const PlanOp& g = net->ops[gi];
+          const bool cat = g.src1 >= 0;
+          const int Cg = net->tensors[g.src0].C + (cat ? net->tensors[g.src1].C : 0);
+          const int coff = g.src0 == op.dst ? 0 : net->tensors[g.src0].C;
+          if (cat) {
+            const int cpg = Cg / 32;
+            if (!(net->knobs.gn_epilogue & 4) || g.film_emb_off >= 0 || g.src0 == g.src1 || Cg % 32 || net->tensors[g.src0].C % cpg || net->tensors[g.src1].C % cpg) continue;
+          }
+          if (!c.act_out) {
+            c.act_out = TP(g.dst); c.act_gamma = WF(g.gamma_off) + coff; c.act_beta = WF(g.beta_off) + coff;
+            if (g.film_emb_off >= 0) { c.act_film = embp + g.film_emb_off; c.act_film_stride = estride; }
+            c.act_silu = g.pro_silu; c.act_stride = Cg; c.act_coff = coff; c.act_cpg = Cg / 32;
+            if (!cat || coff == 0) warm_next(g, c.warm, c.warm_bytes, 1);
+            fused_site[0] = gi;
+          } else if (!c.act2_out && g.film_emb_off < 0) {
+            c.act2_out = TP(g.dst); c.act2_gamma = WF(g.gamma_off) + coff; c.act2_beta = WF(g.beta_off) + coff;
+            c.act2_silu = g.pro_silu; c.act2_stride = Cg; c.act2_coff = coff; c.act2_cpg = Cg / 32;
+            fused_site[1] = gi;
+          }
+        }
+        if (c.act_out) {
+          // the raw tensor is written unless the one site asked for is its only reader (with two sites asked for the launch may still take one)
+          c.act_raw = c.act2_out ? 1 : readers[op.dst] > 1;
           try_act = true;
         }
       }
       rc = conv_launch(c, stream, &slots, try_act ? &act_done : nullptr);
-      if (act_done) { gn_done[oi + 1] = 1; if (act_consumer) pro_off[act_consumer] = 1; }
+      if (act_done && act_consumer) { gn_done[oi + 1] = 1; pro_off[act_consumer] = 1; }
+      else if (act_done) {
+        for (int k = 0; k < 2; ++k) {
+          if (!(act_done & (1 << k)) || fused_site[k] < 0) continue;
+          const PlanOp& g = net->ops[fused_site[k]];
+          if (++site_parts[fused_site[k]] == (g.src1 >= 0 ? 2 : 1)) gn_done[fused_site[k]] = 1;
+        }
+      }
       if (op.dst >= 0 && (size_t)op.dst < net->tensor_state_n) net->tensor_state[op.dst].store((char)(!act_done ? 0 : (act_consumer ? 2 : (c.act_raw ? 0 : 1))), std::memory_order_relaxed);
       if (op.dst >= 0) gn_slots[op.dst] = slots;
       if (run.prof) {

@@ -69,10 +69,12 @@ typedef struct mi355_debug_config {
   int32_t gn_fuse;         /* 1: GroupNorm statistics come from partial sums in the producing convs' epilogues where possible */
   int32_t l2_warm;         /* 1: bit 0: statistics / apply passes touch the next conv's weights; bit 1: finalize passes too */
   int32_t attn_fused;      /* bit 0: GroupNorm-apply + qkv + attention in one kernel where the shape allows; bit 1: never its persistent form; bits 8..: image lanes of the persistent form (tests) */
-  int32_t gn_epilogue;     /* 3: bit 0: at the 8x8 / 4x4 levels a GroupNorm (+SiLU) site whose only source is a small-level conv's output is applied in
+  int32_t gn_epilogue;     /* 7: bit 0: at the 8x8 / 4x4 levels a GroupNorm (+SiLU) site whose only source is a small-level conv's output is applied in
                             *    that conv's epilogue (no pass); bit 1: at the 16x16 level (a persistent-conv tile = a whole image) the first conv of
                             *    a ResBlock normalises its own output in place (its own template instantiation), the site's finalize launch
-                            *    disappears and the second conv runs prologue-free; 0: gn_affine pass / finalize launch + prologue */
+                            *    disappears and the second conv runs prologue-free; bit 2 (with bit 0): at the 8x8 / 4x4 levels the norm of a CONCAT consumer
+                            *    (unet.py:650; groups whole inside each source) is applied by the two producers, each its own channels - a skip
+                            *    connection's conv then serves two sites in one epilogue; 0: gn_affine pass / finalize launch + prologue */
   int32_t conv_pp;         /* 13: the ping-pong 3x3 kernel (conv_pp.inc.h: 8 MFMA waves in two groups that alternate LDS-read / DMA segments with MFMA
                             *    segments).  Bits 0-1: 1 = it takes an eligible conv when the launch has at least one tile per CU, 2 = whenever the
                             *    shape is eligible (tests), 0 = never.  Bit 2 (4): wide-geometry convs (Cout % 256 == 0) with a GroupNorm + SiLU input

@@ -603,6 +603,54 @@ def test_groupnorm_in_small_conv_epilogue_matches_pass(film):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("film", [False, True])
+def test_concat_groupnorm_applied_by_both_producers(film):
+    """Up path, 8x8 / 4x4 levels: h = cat([h, hs.pop()]) (unet.py:650) goes through the in_layers GroupNorm32 + SiLU of the next ResBlock
+    (unet.py:196-200; nn.py:87-94).  512 channels in 32 groups = 16 per group, 256 per source: the groups are whole inside each source, so
+    the norm of the concat is the norm of h's channels (gamma[0:256]) next to the norm of the skip connection's (gamma[256:512]).  Bit 2 of
+    gn_epilogue lets the two producing convs write their halves of the activated concat tensor from their epilogues - the skip connection's
+    conv, much earlier in the walk, then serves two sites (its own next norm, 8 channels per group, and this one, 16) - and the gn_affine
+    pass of the site disappears.  Same forward with the bit off: fp32 to rounding; bf16 not worse against the fp32 result; six launches
+    fewer at B = 256 (three sites per level)."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import debug_config
+
+    kw = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+              channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64, use_scale_shift_norm=film)
+    sd = None
+
+    def run(precision, B, **knobs):
+        nonlocal sd
+        net = UNetModel(precision=precision, **kw)
+        if sd is None:
+            sd = synth_state_dict(param_shapes(net), 5301)
+        net.load_state_dict(sd)
+        net.debug = debug_config(**knobs)
+        net.to(DEV)
+        x = randn(5300, B, 3, 32, 32).to(DEV)
+        t = torch.linspace(0, 1, B).to(DEV)
+        e = net.engine(DEV)
+        y = e.forward(x, t).cpu()
+        torch.cuda.synchronize(); e.check()
+        return y, e.stats(B)["launches"]
+
+    for B in (256, 258, 8):
+        a, la = run("fp32", B, gn_epilogue=7)
+        b, lb = run("fp32", B, gn_epilogue=3)
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=5e-5)
+        if B == 256:
+            assert lb - la == 6, (la, lb)
+    for prec in ("bf16", "fp16"):
+        a, _ = run(prec, 256, gn_epilogue=7)
+        b, _ = run(prec, 256, gn_epilogue=3)
+        ref, _ = run("fp32", 256, gn_epilogue=0)
+        scale = ref.abs().max().item()
+        ea, eb = (a - ref).pow(2).mean().sqrt().item(), (b - ref).pow(2).mean().sqrt().item()
+        assert ea < 0.02 * scale and ea < 1.5 * eb + 1e-3 * scale, (prec, ea, eb, scale)
+
+
+@pytest.mark.gpu
 def test_groupnorm_in_place_at_16x16_matches_launch_and_read_tensor_reports_it():
     """At the 16x16 level a persistent-conv tile is a whole image, so the first conv of a ResBlock (unet.py:283-286) applies the out_layers
     GroupNorm + SiLU (unet.py:306-311; GroupNorm32 nn.py:11-13) to its own accumulators and stores the result IN PLACE (its own template
