@@ -56,6 +56,10 @@ struct ConvKArgs {
   int act_stride, act_coff, act_cpg; uint32_t abytes;   // act_out: channels per pixel, first channel this conv fills, channels per group, bytes
   void* act2_out; const float* act2_gamma; const float* act2_beta; int act2_silu, act2_stride, act2_coff, act2_cpg; uint32_t a2bytes;   // a second site (no FiLM)
   const void* warm; uint32_t warm_bytes;
+  // small-level kernel only: a 1x1 conv of cat(sk0, sk1) (SC0 + SC1 channels at the output resolution) accumulated into the same output - the
+  // ResBlock's skip_connection inside its second conv; w then holds, per 128-channel pack tile, the 3x3 tiles followed by one tile per skip chunk
+  const void* sk0; const void* sk1; int SC0, SC1; uint32_t skbytes0, skbytes1;
+  uint32_t wstride;                  // 8-KB weight tiles per 128-channel pack tile (9 nchunks without a fused skip conv)
 };
 
 #ifdef CONV_STAMPS
@@ -703,6 +707,22 @@ void conv_pack_weights(int dtype, const float* w, int Cout, int Cin, int ks, voi
       }
 }
 
+size_t conv_packed_weight_bytes_skip(int dtype, int Cout, int Cin, int Cskip) {
+  return conv_packed_weight_bytes(dtype, Cout, Cin, 3, 0) + conv_packed_weight_bytes(dtype, Cout, Cskip, 1, 0);
+}
+void conv_pack_weights_skip(int dtype, const float* w3, const float* w1, int Cout, int Cin, int Cskip, void* dst) {
+  const size_t b3 = conv_packed_weight_bytes(dtype, Cout, Cin, 3, 0), b1 = conv_packed_weight_bytes(dtype, Cout, Cskip, 1, 0);
+  std::vector<char> t3(b3), t1(b1);
+  conv_pack_weights(dtype, w3, Cout, Cin, 3, t3.data(), 0);
+  conv_pack_weights(dtype, w1, Cout, Cskip, 1, t1.data(), 0);
+  const size_t nt = (Cout + conv_tile_n(Cout) - 1) / conv_tile_n(Cout), s3 = b3 / nt, s1 = b1 / nt;
+  char* out = reinterpret_cast<char*>(dst);
+  for (size_t t = 0; t < nt; ++t) {
+    memcpy(out + t * (s3 + s1), t3.data() + t * s3, s3);
+    memcpy(out + t * (s3 + s1) + s3, t1.data() + t * s1, s1);
+  }
+}
+
 // Weights of the data-gradient conv (backward w.r.t. the input) of a [Cout][Cin][ks][ks] forward filter: the transposed conv of a
 // stride-1, padding ks/2 convolution is the same convolution with input / output channels swapped and the taps flipped,
 // W'[ci][co][ky][kx] = W[co][ci][ks-1-ky][ks-1-kx]; rows ci >= Cin (channel padding of the forward input) are zero.
@@ -738,19 +758,21 @@ ConvGeom conv_geometry(const ConvDesc& d) {
   return r;
 }
 
-int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* act_done) {
+static int conv_launch_impl(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* act_done, bool dry);
+int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* act_done) { return conv_launch_impl(d, stream, gn_slots_used, act_done, false); }
+// 0: a conv with a fused skip conv (ConvDesc::skip_src0) of this description would launch; nothing is launched
+int conv_fused_skip_ok(const ConvDesc& d) { return d.skip_src0 ? conv_launch_impl(d, nullptr, nullptr, nullptr, true) : 1; }
+
+static int conv_launch_impl(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* act_done, bool dry) {
   if (gn_slots_used) *gn_slots_used = 0;
   if (act_done) *act_done = 0;
-  {
-    const int r = conv1x1_try_launch(d, stream, gn_slots_used);
+  const bool fskip = d.skip_src0 != nullptr;   // only the small-level kernel carries a fused skip conv
+  if (!fskip) {
+    int r = conv1x1_try_launch(d, stream, gn_slots_used);
     if (r <= 0) return r;
-  }
-  {
-    const int r = conv_out_try_launch(d, stream);
+    r = conv_out_try_launch(d, stream);
     if (r <= 0) return r;
-  }
-  {
-    const int r = conv_in_try_launch(d, stream, gn_slots_used);
+    r = conv_in_try_launch(d, stream, gn_slots_used);
     if (r <= 0) return r;
   }
   const int CH = chunk_of(d.dtype);
@@ -772,7 +794,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
   a.w = d.w; a.bias = d.bias; a.Cout = d.Cout; a.bn_pack = g.bn_pack;
   const size_t esz = d.dtype == 0 ? 4 : 2;
   const size_t b0 = (size_t)d.N * d.Hs * d.Ws * d.C0 * esz, b1 = (size_t)d.N * d.Hs * d.Ws * d.C1 * esz;
-  const size_t wb = conv_packed_weight_bytes(d.dtype, d.Cout, Cin, d.ks, d.wsplit);
+  const size_t wb = conv_packed_weight_bytes(d.dtype, d.Cout, Cin, d.ks, d.wsplit) + (fskip ? conv_packed_weight_bytes(d.dtype, d.Cout, d.skip_C0 + d.skip_C1, 1, 0) : 0);
   MI355_REQUIRE(b0 < 0xFFFF0000ull && b1 < 0xFFFF0000ull && wb < 0xFFFF0000ull, -4,
                 "conv: a source tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb;
@@ -791,9 +813,15 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
   a.gn_stats = nullptr; a.gn_slots = 0;
   a.lvw = g.lvw; a.lth = g.lth; a.G = g.G; a.PW = g.PW; a.PH = g.PH; a.NP = g.NP;
   a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
+  if (fskip) {
+    const size_t k0 = (size_t)d.N * g.Ho * g.Wo * d.skip_C0 * esz, k1 = (size_t)d.N * g.Ho * g.Wo * d.skip_C1 * esz;
+    MI355_REQUIRE(k0 < 0xFFFF0000ull && k1 < 0xFFFF0000ull, -4, "conv: a source tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
+    a.sk0 = d.skip_src0; a.sk1 = d.skip_src1; a.SC0 = d.skip_C0; a.SC1 = d.skip_src1 ? d.skip_C1 : 0;
+    a.skbytes0 = (uint32_t)k0; a.skbytes1 = d.skip_src1 ? (uint32_t)k1 : 0u;
+  }
   dim3 grid(g.groups * g.tiles_x * g.tiles_y, (d.Cout + g.BN - 1) / g.BN);
   const bool gn_ok = d.gn_stats && d.out_mode == OUT_NHWC && g.G == 1 && d.Cout % g.BN == 0 && d.Cout % 4 == 0;
-  {   // ping-pong kernel (conv_pp.inc.h): 256- or 128-channel output tiles, input as it is or through the in-LDS GroupNorm + SiLU prologue
+  if (!fskip) {   // ping-pong kernel (conv_pp.inc.h): 256- or 128-channel output tiles, input as it is or through the in-LDS GroupNorm + SiLU prologue
     const int pc = pp_config(K.conv_pp, d.ks, g.G, g.bn_pack, d.out_mode, g.stride, a.nchunks, d.pro_a != nullptr, d.pro_silu != 0, d.N, g.Ho, g.Wo, d.Cout);
     const int pp_slots = pc >= 0 ? pp_gn_slots(pc, g.Ho, g.Wo) : 0;
     if (pc >= 0 && gn_ok && pp_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = pp_slots; }
@@ -813,7 +841,7 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
     a.act_out = nullptr;
     a.gn_stats = nullptr; a.gn_slots = 0;
   }
-  {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
+  if (!fskip) {   // dominant shapes: warp-specialised persistent kernel (conv_ws.inc.h)
     const int ws_slots = 2 * ((g.Wo + ws::VW - 1) / ws::VW) * ((g.Ho + ws::TH - 1) / ws::TH);   // (16x16 pixel tile, 8-row half) per image
     if (gn_ok && ws_slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = ws_slots; }
     const int r = dispatch_dtype(d.dtype, [&](auto t) { return launch_ws<decltype(t)>(a, K.conv_ws, g.BM, g.BN, d.ks, stream); });
@@ -842,8 +870,10 @@ int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used, int* 
       }
       a.warm = (K.l2_warm & 1) ? d.warm : nullptr; a.warm_bytes = a.warm ? d.warm_bytes : 0u;
     }
-    const int r = dispatch_dtype(d.dtype, [&](auto t) { return launch_small<decltype(t)>(a, K.conv_small, d.ks, stream, act_done); });
+    const int r = dispatch_dtype(d.dtype, [&](auto t) { return launch_small<decltype(t)>(a, K.conv_small, d.ks, stream, act_done, dry); });
+    if (dry) return r;
     if (r == 0) { MI355_CHECK_HIP(hipGetLastError()); return 0; }
+    MI355_REQUIRE(!fskip || r < 0, -5, "conv: this launch cannot carry the fused skip conv (ask conv_fused_skip_ok first)");
     if (act_done) *act_done = 0;
     a.act_out = nullptr; a.act2_out = nullptr; a.warm = nullptr; a.warm_bytes = 0;
     if (r < 0) return r;

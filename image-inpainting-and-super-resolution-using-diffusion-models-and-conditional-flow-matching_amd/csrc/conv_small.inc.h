@@ -15,13 +15,16 @@
 //     pixels: conflict-free ds_read_b128 for every tap shift (tools/lds_bank_sim.py; the plain kernel's 96-B rows are 2-way
 //     conflicted on 8-pixel-wide images).
 namespace sm {
-struct Args { int pwp, pimg, sh, plane, nphase, chp, red_bytes; };
+// sphase x schp: centre-tap chunk phases of a fused 1x1 skip conv (0: none); sup: its planes are staged with the main patch instead (one phase, dense
+// 64-pixel x 64-B planes behind the main ones: LDS permitting)
+struct Args { int pwp, pimg, sh, plane, nphase, chp, red_bytes, sphase, schp, sup; };
+constexpr int SPLANE = 4096, SDMAX = 16;   // dense skip plane bytes; at most this many of them
 }  // namespace sm
 
 // NI = 4: four waves of 64 output channels (one per SIMD).  NI = 2 (round 5, whole-chip launches of the 8x8 level): EIGHT waves of 32 channels, two per SIMD - the
 // same bytes through the CU's L1 path, but while one wave of a SIMD waits for its weight fragments the other multiplies (in-kernel stamps of the four-wave
 // form: weight stream alone 9.1 us, MFMAs alone 9.8 us, together 20: they added up instead of overlapping).
-template <typename T, int KSPLIT, int NCHP, int PITU, int NI = 4, int W8_ = (NCHP == 16)>   // W8_: 8x8 output images (one per tile); else four 4x4 images
+template <typename T, int KSPLIT, int NCHP, int PITU, int NI = 4, int W8_ = (NCHP == 16), int SKIP = 0>   // W8_: 8x8 output images (one per tile); else four 4x4 images; SKIP: carries a fused 1x1 skip conv
 __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_small_kernel(ConvKArgs p, sm::Args g) {
   using E = Elem<T>;
   constexpr int CHUNK = E::CHUNK, ESZ = sizeof(T);
@@ -41,6 +44,9 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src1 ? p.src1 : p.src0), 0, p.bytes1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.wbytes, 0x00020000);
+  // fused 1x1 skip conv (ResBlock skip_connection, unet.py:312-317,351: out = skip(x) + conv2(h)): x = cat(sk0, sk1), contracted at the centre tap
+  const __amdgpu_buffer_rsrc_t rk0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sk0 ? p.sk0 : p.src0), 0, p.sk0 ? p.skbytes0 : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sk1 ? p.sk1 : p.src0), 0, p.sk1 ? p.skbytes1 : 0u, 0x00020000);
 
   // ---- weight stream of this wave: chunk sequence s = 0 .. nphase * chw - 1 ----
   const int chw = g.chp / KSPLIT;     // chunks per wave and phase: chunk (ph, j) of this wave = ph * chp + kk * chw + j
@@ -50,24 +56,26 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
     const int row = (co0 & 127) + ni * 16 + lr;
     boff[ni] = row * 64 + 16 * (lq ^ ((row >> 1) & 3));
   }
-  const uint32_t wt0 = (uint32_t)(co0 >> 7) * p.nchunks * 9;   // first (chunk, tap) tile of this wave's 128-channel pack tile
+  // 8-KB tiles of this wave's 128-channel pack tile: (chunk c, tap) at 9 c + tap, then - fused skip conv - one tile per skip chunk
+  const uint32_t wt0 = (uint32_t)(co0 >> 7) * p.wstride;
   u32x4 bring[9][NI] = {};
-  auto issue_b = [&](auto tapc, int c) {
+  auto issue_b = [&](auto tapc, int tile9) {   // ring slot tap <- tile tile9 + tap
     constexpr int tap = decltype(tapc)::value;
-    const uint32_t so = (wt0 + (uint32_t)c * 9 + tap) * 8192u;
+    const uint32_t so = (wt0 + (uint32_t)tile9 + tap) * 8192u;
     if constexpr (WS_ABLATE & 8) return;   // diagnostic builds only (Makefile: variant ABL=<mask>): 4 = no LDS reads / MFMAs, 8 = no weight loads, 16 = no patch staging
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) bring[tap][ni] = buf_load16(rsw, boff[ni], so);
   };
   {
-    const int c = kk * chw;
+    const int c = kk * chw * 9;
     issue_b(IC<0>(), c); issue_b(IC<1>(), c); issue_b(IC<2>(), c); issue_b(IC<3>(), c); issue_b(IC<4>(), c);
     issue_b(IC<5>(), c); issue_b(IC<6>(), c); issue_b(IC<7>(), c); issue_b(IC<8>(), c);
   }
+  const int schw = g.schp / KSPLIT;   // skip chunks per wave and skip phase: chunk (sp, j) of this wave = sp * schp + kk * schw + j, tile 9 nchunks + that
 
   // ---- patch staging geometry: fragment u of this thread = patch pixel (tid + 256 u) >> 2, 16-B quarter (tid + 256 u) & 3 ----
   uint32_t voff0[PITU], voff1[PITU]; int ldst[PITU];
-  {
+  auto patch_geometry = [&](int CA, int CB, uint32_t bytesA, uint32_t bytesB) {   // per-pixel byte offsets into two sources of CA / CB channels
     const int ppi = p.PH * p.PW, npv = p.G * ppi;
     const float inv_ppi = 1.0f / (float)ppi, inv_pw = 1.0f / (float)p.PW;
 #pragma unroll
@@ -84,32 +92,40 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
         dst = lin * 64 + 16 * (q ^ ((lin >> g.sh) & 3));
       }
       ldst[u] = dst;
-      voff0[u] = s >= 0 ? (uint32_t)s * (uint32_t)(p.C0 * ESZ) + q * 16 : p.bytes0;
-      voff1[u] = s >= 0 ? (uint32_t)s * (uint32_t)(p.C1 * ESZ) + q * 16 : p.bytes1;
+      voff0[u] = s >= 0 ? (uint32_t)s * (uint32_t)(CA * ESZ) + q * 16 : bytesA;
+      voff1[u] = s >= 0 ? (uint32_t)s * (uint32_t)(CB * ESZ) + q * 16 : bytesB;
     }
-  }
-  auto stage = [&](int ph) {
+  };
+  patch_geometry(p.C0, p.C1, p.bytes0, p.bytes1);
+  // planes 0 .. nlive - 1 <- channel chunks c0 .. of cat(A, B) (A has CA channels), NB planes' loads in flight at a time
+  auto stage_from = [&](auto nbc, int c0, int nlive, bool wrap, const __amdgpu_buffer_rsrc_t& rA, const __amdgpu_buffer_rsrc_t& rB, int CA, uint32_t bytesA, uint32_t bytesB) {
+    constexpr int NB = decltype(nbc)::value;
     if constexpr (WS_ABLATE & 16) return;
-    u32x4 raw[NCHP][PITU];
 #pragma unroll
-    for (int cl = 0; cl < NCHP; ++cl) {
-      const int cb = src_chunk(p, ph * g.chp + cl) * CHUNK;
-      const bool live = cl < g.chp, first = cb < p.C0;
+    for (int b0 = 0; b0 < NCHP; b0 += NB) {
+      if (b0 >= nlive) break;
+      u32x4 raw[NB][PITU];
 #pragma unroll
-      for (int u = 0; u < PITU; ++u) {
-        const uint32_t vo = live ? (first ? voff0[u] : voff1[u]) : (first ? p.bytes0 : p.bytes1);
-        raw[cl][u] = buf_load16(first ? rs0 : rs1, vo, (uint32_t)(first ? cb : cb - p.C0) * ESZ);
+      for (int cl = 0; cl < NB; ++cl) {
+        const int cb = (wrap ? src_chunk(p, c0 + b0 + cl) : c0 + b0 + cl) * CHUNK;
+        const bool live = b0 + cl < nlive, first = cb < CA;
+#pragma unroll
+        for (int u = 0; u < PITU; ++u) {
+          const uint32_t vo = live ? (first ? voff0[u] : voff1[u]) : (first ? bytesA : bytesB);
+          raw[cl][u] = buf_load16(first ? rA : rB, vo, (uint32_t)(first ? cb : cb - CA) * ESZ);
+        }
       }
-    }
 #pragma unroll
-    for (int cl = 0; cl < NCHP; ++cl) {
-      if (cl < g.chp) {
+      for (int cl = 0; cl < NB; ++cl) {
+        if (b0 + cl < nlive) {
 #pragma unroll
-        for (int u = 0; u < PITU; ++u)
-          if (ldst[u] >= 0) *reinterpret_cast<u32x4*>(smem + cl * g.plane + ldst[u]) = raw[cl][u];
+          for (int u = 0; u < PITU; ++u)
+            if (ldst[u] >= 0) *reinterpret_cast<u32x4*>(smem + (b0 + cl) * g.plane + ldst[u]) = raw[cl][u];
+        }
       }
     }
   };
+  auto stage = [&](int ph) { stage_from(IC<NCHP>(), ph * g.chp, g.chp, true, rs0, rs1, p.C0, p.bytes0, p.bytes1); };
 
   // ---- A fragment addresses of the 9 taps (the swizzle follows the shifted pixel, so every tap has its own) ----
   int aaddr[9][MI];
@@ -130,14 +146,53 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- fused skip conv, planes staged up front: the 64 output pixels' rows of the raw block input, chunk by chunk, dense (rows of 64 B, 16-B
+  // slots XOR-swizzled by the pixel pair: conflict-free ds_read_b128, tools/lds_bank_sim.py); loads issued here, stored behind the main patch's ----
+  constexpr int SDPT = sm::SDMAX / (NT / 256);   // dense planes per thread (a plane is 256 16-B fragments)
+  u32x4 rawd[SKIP ? SDPT : 1];
+  int dstd = 0, saddr[MI] = {};
+  if constexpr (SKIP != 0) {
+    if (g.sup) {
+      const int pp = (tid & 255) >> 2, q = tid & 3, half = tid >> 8;
+      const int tx = pp & VWm, ty = (pp >> p.lvw) & THm, gi = pp >> (p.lvw + p.lth);
+      const int n = n0 + gi;
+      const bool ok = n < p.N && ty < p.Ho && tx < p.Wo;
+      const uint32_t spx = (uint32_t)((n * p.Hs + ty) * p.Ws + tx);
+      const uint32_t oA = ok ? spx * (uint32_t)(p.SC0 * ESZ) + q * 16 : p.skbytes0, oB = ok ? spx * (uint32_t)(p.SC1 * ESZ) + q * 16 : p.skbytes1;
+      dstd = g.chp * g.plane + pp * 64 + 16 * (q ^ ((pp >> 1) & 3));
+#pragma unroll
+      for (int k = 0; k < SDPT; ++k) {
+        const int cl = k * (NT / 256) + half, cb = cl * CHUNK;
+        const bool live = cl < g.schp, first = cb < p.SC0;
+        rawd[k] = buf_load16(first ? rk0 : rk1, live ? (first ? oA : oB) : (first ? p.skbytes0 : p.skbytes1), (uint32_t)(first ? cb : cb - p.SC0) * ESZ);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = mi * 16 + lr;
+        saddr[mi] = m * 64 + 16 * (lq ^ ((m >> 1) & 3));
+      }
+    }
+  }
+
   for (int ph = 0; ph < g.nphase; ++ph) {
     if (ph > 0) __syncthreads();         // every wave has finished reading the previous phase's patch
     stage(ph);
+    if constexpr (SKIP != 0) {
+      if (g.sup && ph == 0) {
+        const int half = tid >> 8;
+#pragma unroll
+        for (int k = 0; k < SDPT; ++k) {
+          const int cl = k * (NT / 256) + half;
+          if (cl < g.schp) *reinterpret_cast<u32x4*>(smem + cl * sm::SPLANE + dstd) = rawd[k];
+        }
+      }
+    }
     __syncthreads();
     for (int j = 0; j < chw; ++j) {
       const int c = ph * g.chp + kk * chw + j;
-      // the chunk whose weights replace this one's in the ring; after the last chunk the ring refills with it again (never used)
-      const int cn = j + 1 < chw ? c + 1 : (ph + 1 < g.nphase ? c + 1 + g.chp - chw : c);
+      // the chunk whose weights replace this one's in the ring; after the last chunk: this wave's first skip chunks, or the same chunk again (never used)
+      const int cn = (j + 1 < chw ? c + 1 : (ph + 1 < g.nphase ? c + 1 + g.chp - chw : c)) * 9;
+      const int cn9 = (SKIP != 0 && j + 1 == chw && ph + 1 == g.nphase) ? p.nchunks * 9 + kk * schw : cn;
       const char* pl = smem + (kk * chw + j) * g.plane;
       u32x4 af[2][MI] = {};
       auto read_a = [&](auto tc) {
@@ -157,10 +212,61 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], bring[t][ni], af[t & 1][mi], T());   // D rows = channels, cols = pixels
         __builtin_amdgcn_sched_barrier(0);
-        issue_b(tc, cn);
+        issue_b(tc, cn9);
       };
       read_a(IC<0>());
       tap(IC<0>()); tap(IC<1>()); tap(IC<2>()); tap(IC<3>()); tap(IC<4>()); tap(IC<5>()); tap(IC<6>()); tap(IC<7>()); tap(IC<8>());
+    }
+  }
+
+  // ---- fused skip conv: phases of centre-tap chunks of the raw block input, nine chunks per pass of the weight ring (the ring slot that was a
+  // tap is now a chunk: tile 9 nchunks + chunk); a slot beyond the wave's chunks holds a tile nobody multiplies ----
+  if constexpr (SKIP != 0) {
+    if (!g.sup) {
+      __syncthreads();                   // main patch dead
+      patch_geometry(p.SC0, p.SC1, p.skbytes0, p.skbytes1);
+    }
+    const int pstep = g.sup ? sm::SPLANE : g.plane;
+    int caddr[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) caddr[mi] = g.sup ? g.chp * g.plane + saddr[mi] : aaddr[4][mi];
+    for (int sp = 0; sp < g.sphase; ++sp) {
+      if (!g.sup) {
+        if (sp > 0) __syncthreads();
+        stage_from(IC<(NCHP >= 8 ? NCHP / 2 : NCHP)>(), sp * g.schp, g.schp, false, rk0, rk1, p.SC0, p.skbytes0, p.skbytes1);
+        __syncthreads();
+      }
+      for (int j0 = 0; j0 < schw; j0 += 9) {
+        const int nvalid = min(9, schw - j0);
+        const int here = sp * g.schp + kk * schw + j0;   // first skip chunk of this pass
+        const int next9 = p.nchunks * 9 + (j0 + 9 < schw ? here + 9 : (sp + 1 < g.sphase ? (sp + 1) * g.schp + kk * schw : here));
+        const char* pl0 = smem + (kk * schw + j0) * pstep;
+        u32x4 af[2][MI] = {};
+        auto read_s = [&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          if constexpr (WS_ABLATE & 4) return;
+          const char* pl = pl0 + (t < nvalid ? t : 0) * pstep;   // (a slot beyond the wave's chunks reads a plane that exists; nobody multiplies it)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) af[t & 1][mi] = *reinterpret_cast<const u32x4*>(pl + caddr[mi]);
+        };
+        auto stap = [&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          if constexpr (t < 8) read_s(IC<t + 1>());
+          __builtin_amdgcn_sched_barrier(0);
+          if (t < nvalid) {
+            if constexpr (WS_ABLATE & 4) { asm volatile("" ::"v"(bring[t][0]), "v"(bring[t][1])); }
+            else
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], bring[t][ni], af[t & 1][mi], T());
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          issue_b(tc, next9);
+        };
+        read_s(IC<0>());
+        stap(IC<0>()); stap(IC<1>()); stap(IC<2>()); stap(IC<3>()); stap(IC<4>()); stap(IC<5>()); stap(IC<6>()); stap(IC<7>()); stap(IC<8>());
+      }
     }
   }
 
@@ -457,11 +563,14 @@ __global__ void __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) conv3x3_
 // pixels per output pixel: 2-way bank conflicts on reads that are a tenth of this kernel's LDS budget), no GroupNorm prologue (these
 // levels normalise in a pass of their own), NHWC output with C_out % 128 == 0, residual at the output resolution or none.
 // 0 = launched, 1 = not eligible (the caller goes on to the plain kernel), < 0 = error
+// dry: eligibility only (the walker decides about a fused skip conv before it reaches the conv that would carry it)
 template <typename T>
-int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* act_done) {
+int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* act_done, bool dry = false) {
   ConvKArgs a = a0;
   if (!enabled || ks != 3 || a.out_mode != OUT_NHWC || a.pro_a) return 1;
   const bool s2 = a.stride == 2;
+  const bool skip = a.sk0 != nullptr;
+  if (skip && (!(enabled & 8) || s2 || a.mode != CONV_UNIT || a.res_mode != RES_NONE || a.src1 || a.nchunks != a.nreal)) return 1;
   if (s2 && (!(enabled & 4) || a.mode != CONV_STRIDE2 || a.Hc != 2 * a.Ho || a.Wc != 2 * a.Wo)) return 1;
   if (a.Ho != a.Wo || (a.Ho != 8 && a.Ho != 4) || a.Cout % 128 != 0) return 1;
   if (a.res_mode != RES_NONE && a.res_mode != RES_SAME) return 1;
@@ -488,8 +597,21 @@ int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* a
   const int ksplit = 4 / nw;
   if (g.chp % ksplit) return 1;
   g.red_bytes = ksplit > 1 ? 4 * 16 * 1024 : 0;
-  const size_t lds = std::max((size_t)g.chp * g.plane, (size_t)g.red_bytes);
+  g.sphase = g.schp = g.sup = 0;
+  a.wstride = (uint32_t)a.nchunks * 9;
+  if (skip) {
+    if (a.SC0 % CH || a.SC1 % CH) return 1;
+    const int ns = (a.SC0 + a.SC1) / CH;
+    g.sup = g.nphase == 1 && ns <= sm::SDMAX && ns % ksplit == 0 && (size_t)g.chp * g.plane + (size_t)ns * sm::SPLANE <= 160 * 1024;
+    g.sphase = g.sup ? 1 : (ns + nchp - 1) / nchp;
+    g.schp = ns / g.sphase;
+    if (g.schp * g.sphase != ns || g.schp % ksplit) return 1;
+    a.wstride += (uint32_t)ns;
+  }
+  const size_t lds = g.sup ? std::max((size_t)g.chp * g.plane + (size_t)g.schp * sm::SPLANE, (size_t)g.red_bytes)
+                           : std::max((size_t)std::max(g.chp, g.schp) * g.plane, (size_t)g.red_bytes);
   if (lds > 160 * 1024) return 1;
+  if (dry) return 0;
   a.gn_stats = nullptr; a.gn_slots = 0;
   {   // GroupNorm of the output in the epilogue: whole images per wave (an 8x8 image split over K-sharing waves is not), 4 / 8 / 16 channels per group
     auto cpg_ok = [&](int cpg, int coff) { return (cpg == 4 || cpg == 8 || cpg == 16) && a.Cout % cpg == 0 && coff % cpg == 0; };
@@ -500,7 +622,7 @@ int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* a
     if (act_done) *act_done = (ok ? 1 : 0) | (ok2 ? 2 : 0);
   }
   // whole-chip launches of the 8x8 level (one image per workgroup, no K split): eight waves of 32 channels (knob conv_small bit 1)
-  const bool w8x2 = w8 && !s2 && ksplit == 1 && (enabled & 2) && a.Cout % 256 == 0;
+  const bool w8x2 = w8 && !s2 && !skip && ksplit == 1 && (enabled & 2) && a.Cout % 256 == 0;
   dim3 grid(tiles, a.Cout / (64 * nw));
   int rc = 0;
   auto go = [&](auto kern, int threads) {
@@ -516,6 +638,16 @@ int launch_small(const ConvKArgs& a0, int enabled, int ks, hipStream_t s, int* a
       if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 4, 6, 4, 0>, 256);
       else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 4, 6, 4, 0>, 256);
       else go(conv3x3_small_kernel<T, 4, 4, 6, 4, 0>, 256);
+    }
+  } else if (skip) {
+    if (w8) {
+      if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 16, 2, 4, 1, 1>, 256);   // (the eight-wave form has no registers left for the skip planes' staging: 240 B of scratch)
+      else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 16, 2, 4, 1, 1>, 256);
+      else go(conv3x3_small_kernel<T, 4, 16, 2, 4, 1, 1>, 256);
+    } else {
+      if (ksplit == 1) go(conv3x3_small_kernel<T, 1, 8, 3, 4, 0, 1>, 256);
+      else if (ksplit == 2) go(conv3x3_small_kernel<T, 2, 8, 3, 4, 0, 1>, 256);
+      else go(conv3x3_small_kernel<T, 4, 8, 3, 4, 0, 1>, 256);
     }
   } else if (w8) {
     if (w8x2) go(conv3x3_small_kernel<T, 1, 16, 1, 2>, 512);

@@ -62,6 +62,10 @@ struct ConvDesc {
   void* act2_out = nullptr; const float* act2_gamma = nullptr; const float* act2_beta = nullptr;
   int act2_silu = 0, act2_stride = 0, act2_coff = 0, act2_cpg = 0;
   const void* warm = nullptr; uint32_t warm_bytes = 0;
+  // Optional (small-level kernel only; ask conv_fused_skip_ok first): out += conv1x1(cat(skip_src0, skip_src1)) - a ResBlock's skip_connection
+  // (unet.py:312-317, 351) inside its second conv: centre-tap K chunks of the raw block input at the output resolution.  w then is the image
+  // conv_pack_weights_skip made, bias the sum of both biases, res none, src1 none.
+  const void* skip_src0 = nullptr; const void* skip_src1 = nullptr; int skip_C0 = 0, skip_C1 = 0;
   int cin_real = 0;                         // > 0: only the first cin_real channels of src0 are non-zero (the network's first conv: in_channels padded to a chunk)
   int wsplit = 0;                           // 1 (bf16x2 precision): w holds [bf16(w) | bf16(w - bf16(w))] along K (twice the chunks): the contraction runs over the
                                             // input channels twice, once against each half - fp32 accumulation of both, activations read (not stored) twice
@@ -80,6 +84,10 @@ int conv_tile_n(int Cout);
 // split = 1 (bf16 only): [hi | lo] halves along K, hi = bf16(w), lo = bf16(w - hi); the chunk count doubles
 void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks, void* dst_host, int split = 0);
 int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr, int* act_done = nullptr);
+int conv_fused_skip_ok(const ConvDesc& d);   // 0 = conv_launch(d) would launch with its fused skip conv (nothing is launched here)
+// [3x3 filter w3 [Cout][Cin][3][3] | 1x1 filter w1 [Cout][Cskip]] per 128-channel pack tile: the 3x3 tiles, then one tile per skip chunk
+size_t conv_packed_weight_bytes_skip(int dtype, int Cout, int Cin, int Cskip);
+void conv_pack_weights_skip(int dtype, const float* w3, const float* w1, int Cout, int Cin, int Cskip, void* dst_host);
 // 1x1 GEMM with a stationary activation tile (conv1x1.hip): 0 = launched, 1 = not eligible, <0 = error
 int conv1x1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr);
 // 1x1 GEMM in the ping-pong structure (conv_pp1.inc.h: 256 pixels x 256 channels, both operands streamed by DMA): same return convention

@@ -41,6 +41,9 @@ struct PlanOp {
   int use_pro = 0, pro_silu = 0; int emb_off = -1; int res = -1, res_mode = 0; int out_mode = 0;
   // attention
   int heads = 0, ch = 0;
+  // small levels: a ResBlock's 1x1 skip_connection op names the second conv that can carry it (carrier), and that conv names the skip op
+  // (skip_op) and holds the fused weight image / summed bias (conv_pack_weights_skip); decided per launch (conv_fused_skip_ok)
+  int carrier = -1, skip_op = -1; size_t wf_off = 0, bf_off = 0;
 };
 
 struct mi355_unet {

@@ -195,7 +195,31 @@ struct Walker {
       err = "identity skip over a channel concat is not supported";
       return -1;
     }
-    if (y2 >= 0) return add_conv(p + ".out_layers.3", y2, -1, cout, cout, 3, CONV_UNIT, false, 0, 0, -1, res, res_mode, OUT_NHWC);
+    const int skip_idx = cin != cout ? (int)net->ops.size() - 1 : -1;
+    if (y2 >= 0) {
+      const int out = add_conv(p + ".out_layers.3", y2, -1, cout, cout, 3, CONV_UNIT, false, 0, 0, -1, res, res_mode, OUT_NHWC);
+      // Small levels (apply-type norms: the second conv reads one already-activated tensor): the 1x1 skip_connection can ride in the
+      // second conv as centre-tap K chunks of the raw block input (unet.py:312-317, 351: return skip_connection(x) + h), if the launch
+      // agrees (conv_fused_skip_ok: the small-level kernel, conv_small bit 3).  Both weight images are kept.
+      if (out >= 0 && skip_idx >= 0 && net->ops[skip_idx].ks == 1 && !cfg.differentiable && !net->wsplit && cout % 128 == 0) {
+        const int conv2_idx = (int)net->ops.size() - 1;
+        PlanOp& c2 = net->ops[conv2_idx];
+        const float* w3 = P(p + ".out_layers.3.weight", {cout, cout, 3, 3});
+        const float* w1 = P(p + ".skip_connection.weight", {cout, cin, 1, 1});
+        const float* b3 = P(p + ".out_layers.3.bias", {cout});
+        const float* b1 = P(p + ".skip_connection.bias", {cout});
+        c2.wf_off = alloc(conv_packed_weight_bytes_skip(dtype, cout, cout, cin));
+        c2.bf_off = alloc((size_t)cout * 4);
+        if (!dry && w3 && w1 && b3 && b1) {
+          conv_pack_weights_skip(dtype, w3, w1, cout, cout, cin, blob.data() + c2.wf_off);
+          float* bs = reinterpret_cast<float*>(blob.data() + c2.bf_off);
+          for (int i = 0; i < cout; ++i) bs[i] = b3[i] + b1[i];
+        }
+        c2.skip_op = skip_idx;
+        net->ops[skip_idx].carrier = conv2_idx;
+      }
+      return out;
+    }
     return add_conv(p + ".out_layers.3", h1, -1, cout, cout, 3, CONV_UNIT, false, 1, 1, -1, res, res_mode, OUT_NHWC);
   }
 
@@ -536,6 +560,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   // GroupNorm sites the producing conv applied in its epilogue (small levels: ConvDesc::act_out); a tensor's raw copy is written only
   // if an op other than that site reads it
   std::vector<char> gn_done(net->ops.size(), 0);
+  std::vector<char> skip_fused(net->ops.size(), 0);   // second convs of small-level ResBlocks that carry the block's 1x1 skip conv in THIS forward
   std::vector<char> pro_off(net->ops.size(), 0);   // convs whose input arrives already normalised (16x16 level: applied IN PLACE by the producer)
   std::vector<int> readers(net->tensors.size(), 0);
   // apply-type GroupNorm sites (small images) by the tensors they read, and how many of a site's sources their producers have already applied
@@ -607,6 +632,22 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       rc = gn_affine_launch(g, stream);
       r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W;
       r.bytes = (double)B * s0.H * s0.W * (s0.C + C1) * esz * (op.dst >= 0 ? 2 : 1);
+    } else if (op.kind == OP_CONV && op.carrier >= 0 && [&]() {
+                 // 1x1 skip_connection of a small-level ResBlock: does the second conv's launch take it along?  (same description as below,
+                 // as far as eligibility looks: shapes, batch, precision, knobs)
+                 const PlanOp& c2 = net->ops[op.carrier];
+                 const PlanTensor& y2 = net->tensors[c2.src0];
+                 ConvDesc c; c.dtype = dtype; c.src0 = TP(c2.src0); c.C0 = y2.C; c.N = B; c.Hs = y2.H; c.Ws = y2.W; c.mode = c2.mode; c.ks = c2.ks;
+                 c.wsplit = net->wsplit; c.w = W + c2.wf_off; c.bias = WF(c2.bf_off); c.Cout = c2.Cout; c.out_mode = c2.out_mode; c.out = TP(c2.dst);
+                 c.knobs = &net->knobs; c.err = net->err_dev;
+                 c.skip_src0 = TP(op.src0); c.skip_C0 = s0.C; c.skip_src1 = TP(op.src1); c.skip_C1 = C1;
+                 return conv_fused_skip_ok(c) == 0;
+               }()) {
+      skip_fused[op.carrier] = 1;   // nothing to launch: the tensor is never written
+      gn_done[(size_t)(&op - net->ops.data())] = 1;   // (counts as a launch that did not happen)
+      if (op.dst >= 0 && (size_t)op.dst < net->tensor_state_n) net->tensor_state[op.dst].store((char)1, std::memory_order_relaxed);
+      rc = 0;
+      r.kind = MI355_OP_CONV; r.ks = op.ks; r.cin = s0.C + C1; r.cout = op.Cout; r.h = s0.H; r.w = s0.W;
     } else if (op.kind == OP_CONV) {
       ConvDesc c; c.dtype = dtype; c.src0 = TP(op.src0); c.C0 = s0.C; c.src1 = TP(op.src1); c.C1 = C1;
       c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks; c.wsplit = net->wsplit;
@@ -623,6 +664,12 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       c.out_mode = op.out_mode;
       c.knobs = &net->knobs; c.err = net->err_dev;
       c.out = op.out_mode == OUT_NHWC ? TP(op.dst) : (void*)out;
+      if (skip_fused[oi]) {   // the ResBlock's 1x1 skip conv rides in this launch (its op was skipped above)
+        const PlanOp& sk = net->ops[op.skip_op];
+        c.skip_src0 = TP(sk.src0); c.skip_C0 = net->tensors[sk.src0].C;
+        c.skip_src1 = TP(sk.src1); c.skip_C1 = sk.src1 >= 0 ? net->tensors[sk.src1].C : 0;
+        c.w = W + op.wf_off; c.bias = WF(op.bf_off); c.res = nullptr; c.res_mode = RES_NONE;
+      }
       int slots = 0, act_done = 0;
       if (op.dst >= 0 && net->tensors[op.dst].stats_cap) { c.gn_stats = SP(op.dst); c.gn_slots_cap = net->tensors[op.dst].stats_cap; }
       bool try_act = false;

@@ -57,8 +57,9 @@ const char* mi355_last_error(void);
  * the test ops: the library reads no environment variable and keeps no process-global switch. */
 typedef struct mi355_debug_config {
   int32_t conv_ws;         /* 1: 3x3 convs of the large levels run on the persistent warp-specialised kernel (conv_ws.inc.h); 0: plain tiles */
-  int32_t conv_small;      /* 7: bit 0: 8x8 / 4x4 levels run on the LDS-resident-patch kernel (conv_small.inc.h); bit 1: its whole-chip 8x8 launches use eight
-                            *    waves of 32 channels (two per SIMD) instead of four of 64; bit 2: the stride-2 Downsample convs 16 -> 8 and 8 -> 4 too */
+  int32_t conv_small;      /* 15: bit 0: 8x8 / 4x4 levels run on the LDS-resident-patch kernel (conv_small.inc.h); bit 1: its whole-chip 8x8 launches use eight
+                            *    waves of 32 channels (two per SIMD) instead of four of 64; bit 2: the stride-2 Downsample convs 16 -> 8 and 8 -> 4 too;
+                            *    bit 3: a ResBlock's 1x1 skip_connection rides in the block's second 3x3 conv as centre-tap K chunks (no launch, no tensor) */
   int32_t conv_min_wgs;    /* 512: the plain kernel takes the largest tile that still yields this many workgroups */
   int32_t conv_stagger;    /* 0: plain kernel: start delay of the odd workgroup slot; persistent kernel: wave priorities (consumer | loader << 2) */
   int32_t conv_ablate;     /* 0: timing experiments, results become wrong: 1 no output stores, 2 no prologue math, 32 the loaders never

@@ -651,6 +651,52 @@ def test_concat_groupnorm_applied_by_both_producers(film):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("film", [False, True])
+def test_skip_connection_rides_in_second_conv_at_small_levels(film):
+    """ResBlock with a channel change (up path: 512 -> 256 over the concat): return skip_connection(x) + out_layers(h) (unet.py:312-317, 351).
+    At the 8x8 / 4x4 levels the 1x1 skip_connection launch (9-12 us, launch-bound) disappears: the block's second 3x3 conv contracts the raw
+    block input cat(h, skip) at its centre tap as extra K chunks (conv_small bit 3; the weight image holds the 3x3 tiles followed by one tile
+    per skip chunk, the bias is the sum of both).  Same forward with the bit off: fp32 to rounding (the sum is now formed in the fp32
+    accumulators instead of through a stored tensor); bf16 / fp16 not worse against fp32 (one rounding fewer); six launches fewer at
+    B = 256.  B = 8 runs the K-sharing forms of both levels, B = 258 a ragged last 4x4 tile, B = 1100 the 4x4 form without K sharing."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import debug_config
+
+    kw = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(2,),
+              channel_mult=(1, 2, 2, 2), num_heads=4, num_head_channels=64, use_scale_shift_norm=film)
+    sd = None
+
+    def run(precision, B, **knobs):
+        nonlocal sd
+        net = UNetModel(precision=precision, **kw)
+        if sd is None:
+            sd = synth_state_dict(param_shapes(net), 5401)
+        net.load_state_dict(sd)
+        net.debug = debug_config(**knobs)
+        net.to(DEV)
+        x = randn(5400, B, 3, 32, 32).to(DEV)
+        t = torch.linspace(0, 1, B).to(DEV)
+        e = net.engine(DEV)
+        y = e.forward(x, t).cpu()
+        torch.cuda.synchronize(); e.check()
+        return y, e.stats(B)["launches"]
+
+    for B in (256, 258, 8, 1100):
+        a, la = run("fp32", B, conv_small=15)
+        b, lb = run("fp32", B, conv_small=7)
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=5e-5)
+        assert lb - la == 6, (B, la, lb)
+    for prec in ("bf16", "fp16"):
+        a, _ = run(prec, 256, conv_small=15)
+        b, _ = run(prec, 256, conv_small=7)
+        ref, _ = run("fp32", 256, conv_small=7)
+        scale = ref.abs().max().item()
+        ea, eb = (a - ref).pow(2).mean().sqrt().item(), (b - ref).pow(2).mean().sqrt().item()
+        assert ea < 0.02 * scale and ea < 1.2 * eb + 1e-3 * scale, (prec, ea, eb, scale)
+
+
+@pytest.mark.gpu
 def test_groupnorm_in_place_at_16x16_matches_launch_and_read_tensor_reports_it():
     """At the 16x16 level a persistent-conv tile is a whole image, so the first conv of a ResBlock (unet.py:283-286) applies the out_layers
     GroupNorm + SiLU (unet.py:306-311; GroupNorm32 nn.py:11-13) to its own accumulators and stores the result IN PLACE (its own template
