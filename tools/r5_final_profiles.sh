@@ -12,6 +12,7 @@ run() { echo "== $*" >> $O/bench_log.txt; python bench.py "$@" 2>>$O/bench_log.t
 run --steps 10 --warmup 3 --profile-out $O/per_op_cifar_b256.json || exit 1
 run --steps 2 --warmup 1 --precision fp32 --no-cpu-baseline || exit 1
 run --steps 5 --warmup 2 --precision bf16x2 --no-cpu-baseline || exit 1
+run --steps 5 --warmup 2 --precision fp16 --no-cpu-baseline || exit 1
 run --steps 3 --warmup 1 --batch 512 --no-cpu-baseline || exit 1
 run --steps 3 --warmup 1 --workload cifar10_inpaint_ddpm50_b512 || exit 1
 run --steps 3 --warmup 1 --workload cifar10_inpaint_ddim50_b512 || exit 1
