@@ -35,7 +35,7 @@ void mi355_debug_defaults(mi355_debug_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
   c->conv_ws = 1; c->conv_small = 15; c->conv_min_wgs = 512; c->conv_stagger = 0; c->conv_ablate = 0; c->conv_spin_limit = 1 << 22;
-  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 7; c->conv_pp = 13; c->conv_edge = 3;
+  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 7; c->conv_pp = 13; c->conv_edge = 15;
 }
 int mi355_unet_status(mi355_unet* net, int clear) {
   if (!net) { mi355_set_error("null handle"); return -1; }
@@ -245,8 +245,8 @@ int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const floa
     int rc;
     if (emb_table) run.emb_row = emb_table + (size_t)k * net->emb_total;
     else if ((rc = fill_launch(sc.t, t, batch, s))) return rc;
+    run.euler_x = x; run.euler_dt = dt;   // x += dt * v: in the last conv's epilogue, or as a launch of unet_forward's own behind it
     if ((rc = unet_forward(net, x, x_channels, cond, cond_channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s, run))) return rc;
-    if ((rc = euler_step_launch(x, sc.v, dt, n, s))) return rc;
     if (cdrift && (rc = euler_step_launch(cdrift, cdrift, dt, nc, s))) return rc;
     if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * n, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
   }

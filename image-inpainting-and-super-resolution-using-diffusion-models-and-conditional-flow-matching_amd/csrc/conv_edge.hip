@@ -26,6 +26,7 @@ struct OutArgs {
   float* out;
   uint32_t bytes_src, wbytes;
   int tiles_x, tiles_y, ntiles;
+  float* axpy_x; float axpy_scale;   // non-null: x += scale * v instead of storing v (same element order as out)
 };
 
 // GN affine (+ SiLU) of one 16-byte fragment.  bf16: fp32 math on element PAIRS (v_pk_fma / v_pk_mul / v_pk_add_f32: two elements per VALU
@@ -186,7 +187,14 @@ __global__ void __launch_bounds__(256) conv3x3_out_kernel(OutArgs p) {
       if (y < p.H && x < p.W) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (j < p.Cout) p.out[(((size_t)n0 * p.Cout + j) * p.H + y) * p.W + x] = acc[mi][j] + (p.bias ? p.bias[j] : 0.f);
+          if (j < p.Cout) {
+            const size_t oi = (((size_t)n0 * p.Cout + j) * p.H + y) * p.W + x;
+            const float v = acc[mi][j] + (p.bias ? p.bias[j] : 0.f);
+            if (p.axpy_x) {
+#pragma clang fp contract(off)   // (the expression of steps.hip euler_step_launch, rounded the same way)
+              p.axpy_x[oi] = p.axpy_x[oi] + p.axpy_scale * v;
+            } else p.out[oi] = v;
+          }
       }
     }
   }
@@ -203,6 +211,7 @@ struct InArgs {
   const void* src; const void* w; const float* bias; void* out;
   float* gn_stats; int gn_slots;
   int N, H, W, tiles_x, tiles_y;
+  const float* x0; const float* x1; int c0, c1;   // x0 non-null: the source is cat(x0, x1) in fp32 NCHW (c0 + c1 <= 8 channels), src unused
 };
 
 template <bool GN, typename T = bf16>   // T: bf16 or f16
@@ -228,8 +237,18 @@ __global__ void __launch_bounds__(256, 4) conv3x3_in_kernel(InArgs p) {
     const int py = q / PW, px = q - py * PW;
     const int gy = ty * 16 + py - 1, gx = tx * 16 + px - 1;
     u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (q < NPX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-      v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.src) + (((size_t)n * p.H + gy) * p.W + gx) * 64);
+    if (q < NPX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+      if (p.x0) {   // what pack_nhwc would have written to this pixel's first slot: the real channels, rounded to T, zeros behind them
+        float f[8];
+        const size_t hw = (size_t)p.H * p.W, px0 = (size_t)gy * p.W + gx;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          f[c] = c < p.c0 ? p.x0[((size_t)n * p.c0 + c) * hw + px0] : (c < p.c0 + p.c1 ? p.x1[((size_t)n * p.c1 + (c - p.c0)) * hw + px0] : 0.f);
+        v = float_to_frag(f, T());
+      } else {
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.src) + (((size_t)n * p.H + gy) * p.W + gx) * 64);
+      }
+    }
     *reinterpret_cast<u32x4*>(xl + q * 16) = v;
   }
   __syncthreads();
@@ -321,6 +340,7 @@ int conv_out_try_launch(const ConvDesc& d, hipStream_t stream) {
   a.src = d.src0; a.C = d.C0; a.N = d.N; a.H = d.Hs; a.W = d.Ws;
   a.pro_a = d.pro_a; a.pro_b = d.pro_b; a.pro_silu = d.pro_silu;
   a.w = d.w; a.bias = d.bias; a.Cout = d.Cout; a.out = reinterpret_cast<float*>(d.out);
+  a.axpy_x = (K.conv_edge & 8) ? d.axpy_x : nullptr; a.axpy_scale = d.axpy_scale;
   const size_t bs = (size_t)d.N * d.Hs * d.Ws * d.C0 * esz, wb = conv_packed_weight_bytes(d.dtype, d.Cout, d.C0, 3);
   MI355_REQUIRE(bs < 0xFFFF0000ull, -4, "conv (out): the source tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes_src = (uint32_t)bs; a.wbytes = (uint32_t)wb;
@@ -335,18 +355,34 @@ int conv_out_try_launch(const ConvDesc& d, hipStream_t stream) {
   rc = dispatch_dtype(d.dtype, [&](auto t) { using T = decltype(t); return fixed ? go(conv3x3_out_kernel<T, true>) : go(conv3x3_out_kernel<T, false>); });
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
+  if (a.axpy_x && d.axpy_done) *d.axpy_done = 1;
   return 0;
 }
 
 // The first conv (see conv3x3_in_kernel).  0 = launched, 1 = not eligible, < 0 = error.  Switch: mi355_debug_config::conv_edge bit 1.
+static bool conv_in_eligible(const ConvDesc& d);
+int conv_in_reads_nchw(const ConvDesc& d) {
+  const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
+  return (d.nchw0 && (K.conv_edge & 4) && d.nchw_c0 >= 1 && d.nchw_c0 + d.nchw_c1 == d.cin_real && (d.nchw_c1 == 0 || d.nchw1) && conv_in_eligible(d)) ? 0 : 1;
+}
+static bool conv_in_eligible(const ConvDesc& d) {
+  const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
+  if (!(K.conv_edge & 2) || d.wsplit) return false;
+  if (d.dtype == DT_F32 || d.ks != 3 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.src1 || d.res || d.emb || d.pro_a || d.act_out) return false;
+  if (d.cin_real < 1 || d.cin_real > 8 || d.C0 != 32 || d.Cout != 128 || conv_tile_n(d.Cout) != 128 || !d.bias) return false;
+  if (d.Hs % 16 != 0 || d.Ws % 16 != 0) return false;
+  return true;
+}
 int conv_in_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used) {
   const mi355_debug_config& K = d.knobs ? *d.knobs : mi355_default_debug();
+  if (d.nchw0) MI355_REQUIRE(conv_in_reads_nchw(d) == 0, -5, "conv (in): this launch cannot read the fp32 NCHW input itself (ask conv_in_reads_nchw first)");
   if (!(K.conv_edge & 2) || d.wsplit) return 1;
   if (d.dtype == DT_F32 || d.ks != 3 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.src1 || d.res || d.emb || d.pro_a || d.act_out) return 1;
   if (d.cin_real < 1 || d.cin_real > 8 || d.C0 != 32 || d.Cout != 128 || conv_tile_n(d.Cout) != 128 || !d.bias) return 1;
   if (d.Hs % 16 != 0 || d.Ws % 16 != 0) return 1;
   InArgs a;
   a.src = d.src0; a.w = d.w; a.bias = d.bias; a.out = d.out;
+  a.x0 = d.nchw0; a.x1 = d.nchw_c1 ? d.nchw1 : nullptr; a.c0 = d.nchw_c0; a.c1 = d.nchw1 ? d.nchw_c1 : 0;
   a.N = d.N; a.H = d.Hs; a.W = d.Ws; a.tiles_x = d.Ws / 16; a.tiles_y = d.Hs / 16;
   const int slots = a.tiles_x * a.tiles_y * 4;
   a.gn_stats = nullptr; a.gn_slots = 0;

@@ -66,6 +66,12 @@ struct ConvDesc {
   // (unet.py:312-317, 351) inside its second conv: centre-tap K chunks of the raw block input at the output resolution.  w then is the image
   // conv_pack_weights_skip made, bias the sum of both biases, res none, src1 none.
   const void* skip_src0 = nullptr; const void* skip_src1 = nullptr; int skip_C0 = 0, skip_C1 = 0;
+  // Optional, the network's two edge convs (conv_edge.hip), sampler loops: (i) first conv: the caller's fp32 NCHW tensors x (nchw_c0 channels)
+  // and condition (nchw_c1) read directly while the patch is staged - src0's packed NHWC copy (pack_nhwc) is then never made
+  // (conv_in_reads_nchw says whether the launch would); (ii) last conv (NCHW fp32 output v): axpy_x += axpy_scale * v instead of storing
+  // v - the Euler update x <- x + dt v of the flow-matching sampler (mnist/utils_mnist2.py:118-138) in the epilogue; *axpy_done = 1 if done
+  const float* nchw0 = nullptr; const float* nchw1 = nullptr; int nchw_c0 = 0, nchw_c1 = 0;
+  float* axpy_x = nullptr; float axpy_scale = 0.f; int* axpy_done = nullptr;
   int cin_real = 0;                         // > 0: only the first cin_real channels of src0 are non-zero (the network's first conv: in_channels padded to a chunk)
   int wsplit = 0;                           // 1 (bf16x2 precision): w holds [bf16(w) | bf16(w - bf16(w))] along K (twice the chunks): the contraction runs over the
                                             // input channels twice, once against each half - fp32 accumulation of both, activations read (not stored) twice
@@ -84,6 +90,7 @@ int conv_tile_n(int Cout);
 // split = 1 (bf16 only): [hi | lo] halves along K, hi = bf16(w), lo = bf16(w - hi); the chunk count doubles
 void conv_pack_weights(int dtype, const float* w_host, int Cout, int Cin, int ks, void* dst_host, int split = 0);
 int conv_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_used = nullptr, int* act_done = nullptr);
+int conv_in_reads_nchw(const ConvDesc& d);    // 0 = conv_launch(d) with nchw0 set would take the first-conv kernel and read the fp32 NCHW tensors itself
 int conv_fused_skip_ok(const ConvDesc& d);   // 0 = conv_launch(d) would launch with its fused skip conv (nothing is launched here)
 // [3x3 filter w3 [Cout][Cin][3][3] | 1x1 filter w1 [Cout][Cskip]] per 128-channel pack tile: the 3x3 tiles, then one tile per skip chunk
 size_t conv_packed_weight_bytes_skip(int dtype, int Cout, int Cin, int Cskip);

@@ -90,8 +90,11 @@ int euler_step_launch(float* x, const float* v, float dt, int64_t n, hipStream_t
   return launch_ew4(n, s, [=] __device__(int64_t i, int64_t, int cnt) {
     float a[4], b[4];
     ld4(x, i, cnt, a); ld4(v, i, cnt, b);
+    {
+#pragma clang fp contract(off)   // product and sum rounded separately, as `x + dt * v` in eager PyTorch (and as conv_edge.hip's fused form of this step)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = a[j] + dt * b[j];
+      for (int j = 0; j < 4; ++j) a[j] = a[j] + dt * b[j];
+    }
     st4(x, i, cnt, a);
   });
 }

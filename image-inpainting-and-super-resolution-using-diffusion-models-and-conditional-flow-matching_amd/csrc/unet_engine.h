@@ -88,6 +88,9 @@ struct UnetRun {
   int t_uniform = 0;   // sampler loops: t[0] holds for the whole batch (one embedding row, stride-0 broadcast)
   const float* emb_row = nullptr;   // sampler loops: this step's row of a precomputed table of all emb_layers outputs
                                     // (unet_embedding_table): the four time-embedding launches are skipped
+  // sampler loops (flow-matching Euler): x += euler_dt * (network output) in the last conv's epilogue where that conv runs on the streaming kernel
+  // (the output tensor is then not written); else unet_forward adds the step launch itself.  euler_x may be the network input x.
+  float* euler_x = nullptr; float euler_dt = 0.f;
   // optional per-op profiling (mi355_unet_profile)
   std::vector<mi355_op_profile>* prof = nullptr;
   std::vector<hipEvent_t>* prof_events = nullptr;

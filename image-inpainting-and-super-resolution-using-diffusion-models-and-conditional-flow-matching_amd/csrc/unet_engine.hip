@@ -560,6 +560,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   // GroupNorm sites the producing conv applied in its epilogue (small levels: ConvDesc::act_out); a tensor's raw copy is written only
   // if an op other than that site reads it
   std::vector<char> gn_done(net->ops.size(), 0);
+  int euler_done = 0;   // the last conv's epilogue applied the sampler's Euler update (UnetRun::euler_x)
   std::vector<char> skip_fused(net->ops.size(), 0);   // second convs of small-level ResBlocks that carry the block's 1x1 skip conv in THIS forward
   std::vector<char> pro_off(net->ops.size(), 0);   // convs whose input arrives already normalised (16x16 level: applied IN PLACE by the producer)
   std::vector<int> readers(net->tensors.size(), 0);
@@ -589,7 +590,23 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
   const float* embp = run.emb_row ? run.emb_row : F(l.embp);
   if (!run.emb_row && (rc = unet_embedding_table(net, t, Be, F(l.embp), F(l.temb), stream))) return rc;
   const int S = net->cfg.image_size;
-  if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
+  // the first conv reads the caller's fp32 NCHW tensors itself where its kernel can (conv_edge bit 2): no packed copy, no pack launch
+  bool in_direct = false;
+  if (!net->cfg.differentiable && readers[net->in_tensor] == 1) {
+    for (const PlanOp& o : net->ops) {
+      if (o.kind != OP_CONV || o.src0 != net->in_tensor) continue;
+      const PlanTensor& ti = net->tensors[net->in_tensor];
+      ConvDesc c; c.dtype = dtype; c.src0 = TP(o.src0); c.C0 = ti.C; c.N = B; c.Hs = ti.H; c.Ws = ti.W; c.mode = o.mode; c.ks = o.ks; c.wsplit = net->wsplit;
+      c.w = W + o.w_off; c.bias = WF(o.bias_off); c.Cout = o.Cout; c.out_mode = o.out_mode; c.out = TP(o.dst); c.knobs = &net->knobs;
+      c.cin_real = net->cfg.in_channels;
+      if (o.use_pro || o.emb_off >= 0 || o.res >= 0 || o.src1 >= 0) break;
+      c.nchw0 = x; c.nchw_c0 = Cx; c.nchw1 = cond; c.nchw_c1 = cond ? Cc : 0;
+      in_direct = conv_in_reads_nchw(c) == 0;
+      break;
+    }
+  }
+  if (in_direct) { if ((size_t)net->in_tensor < net->tensor_state_n) net->tensor_state[net->in_tensor].store((char)1, std::memory_order_relaxed); }
+  else if ((rc = pack_nhwc_launch(dtype, x, Cx, cond, cond ? Cc : 0, B, S * S, net->in_pad, TP(net->in_tensor), stream))) return rc;
   { mi355_op_profile r{}; r.kind = MI355_OP_PRELUDE; mark(r); }
   // the conv a GroupNorm pass feeds is the next op of the plan: the pass warms the L2s with its weights (common.h l2_warm_wave)
   const int warm_mask = net->knobs.l2_warm;   // 1 = statistics / apply passes, 2 = finalize passes (measured: no gain, off)
@@ -658,7 +675,11 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
         c.pro_a = sp; c.pro_b = sp + (size_t)B * net->site_C[op.gn_site];
       }
       c.w = W + op.w_off; c.bias = WF(op.bias_off); c.Cout = op.Cout;
-      if (op.src0 == net->in_tensor) c.cin_real = net->cfg.in_channels;
+      if (op.src0 == net->in_tensor) {
+        c.cin_real = net->cfg.in_channels;
+        if (in_direct) { c.nchw0 = x; c.nchw_c0 = Cx; c.nchw1 = cond; c.nchw_c1 = cond ? Cc : 0; }
+      }
+      if (op.out_mode == OUT_NCHW_F32 && run.euler_x) { c.axpy_x = run.euler_x; c.axpy_scale = run.euler_dt; c.axpy_done = &euler_done; }
       if (op.emb_off >= 0) { c.emb = embp + op.emb_off; c.emb_stride = estride; }
       if (op.res >= 0) { c.res = TP(op.res); c.res_mode = op.res_mode; }
       c.out_mode = op.out_mode;
@@ -769,8 +790,12 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     if (rc) return rc;
     mark(r);
   }
+  if (run.euler_x && !euler_done) {
+    const int64_t n_out = (int64_t)B * net->cfg.out_channels * S * S;
+    if ((rc = euler_step_launch(run.euler_x, out, run.euler_dt, n_out, stream))) return rc;
+  }
   {
-    int64_t skipped = 0;
+    int64_t skipped = in_direct ? 1 : 0;   // (the Euler update is the sampler's launch, not the forward's: not counted either way)
     for (char d : gn_done) skipped += d;
     net->last_launches = net->launches - skipped - (run.emb_row ? 4 : 0);
   }

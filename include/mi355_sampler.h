@@ -84,7 +84,9 @@ typedef struct mi355_debug_config {
                             *    prologue form of the narrow geometry (off: it only ties the warp-specialised kernel).  The 1x1 ping-pong kernel reads bits 0-1 */
   int32_t conv_edge;       /* bit 0: the network's last conv (GroupNorm + SiLU -> 3x3 -> <= 4 channels, NCHW fp32) runs on the streaming kernel of
                             *    conv_edge.hip instead of the generic MFMA tile kernel; bit 1: the first conv (<= 8 real input channels -> 128,
-                            *    bf16) on conv3x3_in_kernel of the same file (contraction over tap x 8 channels instead of tap x padded chunk) */
+                            *    bf16) on conv3x3_in_kernel of the same file (contraction over tap x 8 channels instead of tap x padded chunk); bit 2: that kernel
+                            *    reads the caller's fp32 NCHW x (and condition) itself - no packed NHWC copy, no pack launch; bit 3: in
+                            *    mi355_cfm_euler_sample the update x += dt * v happens in the last conv's epilogue (v is not stored).  Default 15 */
   int32_t reserved[2];
 } mi355_debug_config;
 void mi355_debug_defaults(mi355_debug_config* out);

@@ -697,6 +697,48 @@ def test_skip_connection_rides_in_second_conv_at_small_levels(film):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("in_ch", [3, 6])
+def test_edge_convs_take_the_samplers_copy_and_step(precision, in_ch):
+    """The flow-matching Euler loop (mnist/utils_mnist2.py:118-138: x <- x + dt * model(t, x[, cond])) around the network's two edge convs:
+    conv_edge bit 2 lets the first conv (unet.py:575) read the sampler's fp32 NCHW x (and condition) while it stages its patch, so the packed
+    NHWC copy and its launch disappear; bit 3 applies the update in the last conv's epilogue (unet.py:639-643 -> out), so the field v is never
+    stored and the step launch disappears.  Both are the same arithmetic in the same order: the loop's result must be BIT-identical to the one
+    with the bits off (fp32 mode: only the step moves, its first conv is not the streaming kernel)."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import debug_config
+
+    kw = dict(image_size=32, in_channels=in_ch, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(2,),
+              channel_mult=(1, 2), num_heads=4, num_head_channels=64)
+    sd = None
+    B = 18
+
+    def run(**knobs):
+        nonlocal sd
+        net = UNetModel(precision=precision, **kw)
+        if sd is None:
+            sd = synth_state_dict(param_shapes(net), 5501)
+        net.load_state_dict(sd)
+        net.debug = debug_config(**knobs)
+        net.to(DEV)
+        x = randn(5500, B, 3, 32, 32).to(DEV)
+        cond = randn(5502, B, 3, 32, 32).to(DEV) if in_ch == 6 else None
+        e = net.engine(DEV)
+        y, traj, u8 = e.cfm_euler(x.clone(), [0.0, 0.2, 0.5, 0.6, 1.0], cond=cond, keep_traj=True, want_u8=True)
+        f = e.forward(x, torch.linspace(0, 1, B).to(DEV), cond) if cond is not None else e.forward(x, torch.linspace(0, 1, B).to(DEV))
+        torch.cuda.synchronize(); e.check()
+        return y.cpu(), traj.cpu(), u8.cpu(), f.cpu(), e.stats(B)["launches"]
+
+    a = run(conv_edge=15)
+    b = run(conv_edge=3)
+    assert torch.isfinite(a[0]).all()
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    if precision != "fp32":
+        assert b[4] - a[4] == 1, (a[4], b[4])   # the pack launch of the forward (the step launch is the sampler's)
+
+
+@pytest.mark.gpu
 def test_groupnorm_in_place_at_16x16_matches_launch_and_read_tensor_reports_it():
     """At the 16x16 level a persistent-conv tile is a whole image, so the first conv of a ResBlock (unet.py:283-286) applies the out_layers
     GroupNorm + SiLU (unet.py:306-311; GroupNorm32 nn.py:11-13) to its own accumulators and stores the result IN PLACE (its own template
