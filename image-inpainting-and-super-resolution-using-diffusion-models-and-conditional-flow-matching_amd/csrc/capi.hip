@@ -35,7 +35,7 @@ void mi355_debug_defaults(mi355_debug_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
   c->conv_ws = 1; c->conv_small = 15; c->conv_min_wgs = 512; c->conv_stagger = 0; c->conv_ablate = 0; c->conv_spin_limit = 1 << 22;
-  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 7; c->conv_pp = 13; c->conv_edge = 15;
+  c->conv_time_reps = 0; c->gn_apply_max_hw = 64; c->gn_fuse = 1; c->l2_warm = 1; c->attn_fused = 1; c->gn_epilogue = 7; c->conv_pp = 45; c->conv_edge = 15;
 }
 int mi355_unet_status(mi355_unet* net, int clear) {
   if (!net) { mi355_set_error("null handle"); return -1; }

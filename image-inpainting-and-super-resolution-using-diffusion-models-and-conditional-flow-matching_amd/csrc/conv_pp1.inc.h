@@ -16,8 +16,12 @@ namespace pp1 {
 constexpr int NRING = 4, AHEAD = 3;
 // WIDE = 1: tile 256 pixels x 256 channels, waves 2 (pixels) x 4 (channels); WIDE = 0: 512 pixels x 128 channels, waves 4 x 2 (the 128-channel
 // outputs of the 32x32 level).  A wave tile is 128 pixels x 64 channels either way.
+// WIDE = 2 (round 5): 128 pixels x 256 channels, waves 2 x 4 with a wave tile of 64 pixels x 64 channels - for launches of fewer than two wide tiles
+// per CU (B = 256 at 16x16: one), where the stream had nothing to overlap a tile's residual fetch and stores with: twice the tiles, so the second
+// tile's input streams under the first one's epilogue (the weights are fetched from L2 once more per tile).
 template <int WIDE> struct Cfg {
-  static constexpr int BM = WIDE ? 256 : 512, BN = WIDE ? 256 : 128;
+  static constexpr int BM = WIDE == 2 ? 128 : (WIDE ? 256 : 512), BN = WIDE ? 256 : 128;
+  static constexpr int MIW = WIDE == 2 ? 4 : 8, WPX = 16 * MIW;         // a wave's pixel tiles / pixels
   static constexpr int TAPA = BM * 64, TAPB = BN * 64;                  // one chunk of the activations / of the weights
   static constexpr int PA = BM / 16 / 8, PB = BN / 16 / 8;              // 1-KB DMA pieces per wave and step: 2 + 2 / 4 + 1
   static constexpr int OPS = PA + PB;
@@ -30,6 +34,7 @@ template <typename T, int WIDE>
 __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_mt, int n_nt) {
   using namespace pp1;
   using G = Cfg<WIDE>;
+  constexpr int MIW = G::MIW, WPX = G::WPX;
   constexpr int BM = G::BM, BN = G::BN, TAPA = G::TAPA, TAPB = G::TAPB, PA = G::PA, PB = G::PB, OPS = G::OPS, OFF_A = G::OFF_A, OFF_B = G::OFF_B;
   using E = Elem<T>;
   constexpr int CHUNK = E::CHUNK, ESZ = sizeof(T);
@@ -38,7 +43,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
   const int lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave8 >> 2;                 // 0: waves 0-3, 1: waves 4-7 (the second wave of each SIMD), one tick behind
-  const int wm = WIDE ? grp : wave8 >> 1, wn = WIDE ? wave8 & 3 : wave8 & 1;   // pixels 128 wm .. 128 wm + 127 of the tile, channels 64 wn .. 64 wn + 63
+  const int wm = WIDE ? grp : wave8 >> 1, wn = WIDE ? wave8 & 3 : wave8 & 1;   // pixels WPX wm .. WPX wm + WPX - 1 of the tile, channels 64 wn .. 64 wn + 63
   const int lr = lane & 15, lq = lane >> 4;
   const int TT = p.nchunks;                   // steps per tile (a multiple of 4: the launcher)
   const int HW = p.Ho * p.Wo;                 // a multiple of 256 (the launcher): a tile never straddles two images
@@ -111,12 +116,12 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
   };
 
   // ---------------- fragment addresses (bases made opaque per step: see conv_pp.inc.h) ----------------
-  int a_base = OFF_A + (wm * 128 + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));   // + ring * TAPA (added per step: beyond the 16-bit immediate when WIDE = 0) + mi * 1024
+  int a_base = OFF_A + (wm * WPX + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));   // + ring * TAPA (added per step: beyond the 16-bit immediate when WIDE = 0) + mi * 1024
   int b_base = OFF_B + (wn * 64 + lr) * 64 + 16 * (lq ^ ((lr >> 1) & 3));    // + ring * TAPB + ni * 1024
 
   constexpr bool PAIR = E::DTYPE == 1;
   constexpr int NI = 4, NP2 = PAIR ? NI / 2 : NI, PSTEP = PAIR ? 32 : 16;
-  f32x4 acc[8][NI];
+  f32x4 acc[MIW][NI];
   f32x4 cin[NI];                           // bias (+ per-image embedding) of this lane's channels: the accumulators start from it
   auto cinit_load = [&](int t) {
     int mt, nt;
@@ -133,7 +138,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
   };
   auto acc_init = [&]() {
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = cin[ni];
   };
@@ -147,7 +152,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
 
   // E's vector-memory operations sit inside the window of the next tile's first wait (conv_pp.inc.h): stores (+ residual loads) counted
   // exactly, everything else not at all; fp32 would overflow the 6-bit counter and drains instead.
-  constexpr int EPI_STORES = 8 * NP2;
+  constexpr int EPI_STORES = MIW * NP2;
   const int extra0 = PAIR ? EPI_STORES * (p.res_mode != RES_NONE ? 2 : 1) : 0;
   int extra = 0;
 
@@ -161,14 +166,14 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
     auto step = [&](auto Sc, bool first_q, bool lastq) {
       constexpr int S = decltype(Sc)::value, ringn = (S + AHEAD) % NRING;
       const bool last_of_tile = lastq && S == 3;
-      u32x4 af[8], bf[NI];
+      u32x4 af[MIW], bf[NI];
       {
         int ab = a_base + S * TAPA, bb = b_base;
         asm volatile("" : "+v"(ab), "+v"(bb));
         const char* ap = smem + ab;
         const char* bp = smem + bb;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(ap + mi * 1024);
+        for (int mi = 0; mi < MIW; ++mi) af[mi] = *reinterpret_cast<const u32x4*>(ap + mi * 1024);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const u32x4*>(bp + S * TAPB + ni * 1024);
       }
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
       pp_barrier();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
+      for (int mi = 0; mi < MIW; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) mma16(acc[mi][ni], bf[ni], af[mi], T());   // D rows = channels, cols = pixels
       __builtin_amdgcn_s_setprio(0);
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
       constexpr bool HAS_RES = decltype(resc)::value != 0;
       uint32_t ovo[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ovo[j] = ((uint32_t)(m0 + wm * 128 + (h * 4 + j) * 16 + lr) * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ;
+      for (int j = 0; j < 4; ++j) ovo[j] = ((uint32_t)(m0 + wm * WPX + (h * 4 + j) * 16 + lr) * (uint32_t)p.Cout + (uint32_t)co_s) * ESZ;
       u32x4 rr[4][NP2];
       if constexpr (HAS_RES) {
 #pragma unroll
@@ -266,12 +271,12 @@ __global__ void __launch_bounds__(512, 2) conv1x1_pp_kernel(ConvKArgs p, int n_m
         }
       }
     };
-    auto epi = [&](auto resc, auto gnc) { epi_half(IC<0>(), resc, gnc); epi_half(IC<1>(), resc, gnc); };
+    auto epi = [&](auto resc, auto gnc) { epi_half(IC<0>(), resc, gnc); if constexpr (MIW == 8) epi_half(IC<1>(), resc, gnc); };
     if (p.res_mode != RES_NONE) { if (!do_gn) epi(IC<1>(), IC<0>()); else epi(IC<1>(), IC<1>()); }
     else { if (!do_gn) epi(IC<0>(), IC<0>()); else epi(IC<0>(), IC<1>()); }
-    if (do_gn) {   // slot = (pixel tile of the image, 128-pixel part); quads of this wave's 64 channels
+    if (do_gn) {   // slot = (pixel tile of the image, a wave's pixel part); quads of this wave's 64 channels
       const int rem = (m0 - n0 * HW) / BM;
-      gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * (BM / 128) + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * 64) >> 2)) * 2, lq, lr);
+      gp.store(p.gn_stats + (((size_t)n0 * p.gn_slots + rem * (BM / WPX) + wm) * (size_t)(p.Cout >> 2) + ((nt * BN + wn * 64) >> 2)) * 2, lq, lr);
     }
     acc_init();
     if constexpr (!PAIR) pp_wait_vm<0>();
@@ -299,7 +304,10 @@ static int pp1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_u
   if (!K.conv_pp || d.ks != 1 || d.mode != CONV_UNIT || d.out_mode != OUT_NHWC || d.pro_a) return 1;
   if (d.Cout % 128 != 0 || d.C0 % CH != 0 || d.C1 % CH != 0 || conv_tile_n(d.Cout) != 128) return 1;
   const int wide = d.Cout % 256 == 0;
-  const int BM = wide ? 256 : 512, BN = wide ? 256 : 128;
+  const int HW0 = d.Hs * d.Ws;
+  // half-height wide tiles (conv_pp bit 5) where the wide walk would give a CU fewer than two tiles
+  const bool half = wide && (K.conv_pp & 32) && HW0 % 256 == 0 && (long)d.N * HW0 / 256 * (d.Cout / 256) < 2L * ws_num_cus();
+  const int BM = half ? 128 : (wide ? 256 : 512), BN = wide ? 256 : 128;
   const int Cin = d.C0 + d.C1, nreal = Cin / CH, nchunks = nreal * (d.wsplit ? 2 : 1), HW = d.Hs * d.Ws;
   // (four chunks: the old stationary-tile kernel ties - 128 -> 256 at 16x16: 13.4 vs 13.9 us - and stays)
   if (nchunks < 8 || (nchunks & 3) || (HW % BM) != 0) return 1;
@@ -319,10 +327,10 @@ static int pp1_try_launch(const ConvDesc& d, hipStream_t stream, int* gn_slots_u
                 "conv1x1: a tensor exceeds 4 GiB (32-bit buffer offsets): run the batch in slices");
   a.bytes0 = (uint32_t)b0; a.bytes1 = d.src1 ? (uint32_t)b1 : 0u; a.wbytes = (uint32_t)wb; a.obytes = (uint32_t)ob; a.rbytes = d.res ? (uint32_t)ob : 0u;
   a.ablate = K.conv_ablate; a.err = d.err; a.spin_limit = 1;
-  const int slots = HW / 128;               // (pixel tile of the image, 128-pixel part)
+  const int slots = HW / (half ? 64 : 128);   // (pixel tile of the image, a wave's pixel part)
   if (d.gn_stats && slots <= d.gn_slots_cap) { a.gn_stats = d.gn_stats; a.gn_slots = slots; }
   int rc;
-  rc = dispatch_dtype(d.dtype, [&](auto t) { using T = decltype(t); return wide ? pp1_launch<T, 1>(a, n_mt, n_nt, stream) : pp1_launch<T, 0>(a, n_mt, n_nt, stream); });
+  rc = dispatch_dtype(d.dtype, [&](auto t) { using T = decltype(t); return half ? pp1_launch<T, 2>(a, n_mt, n_nt, stream) : (wide ? pp1_launch<T, 1>(a, n_mt, n_nt, stream) : pp1_launch<T, 0>(a, n_mt, n_nt, stream)); });
   if (rc) return rc;
   MI355_CHECK_HIP(hipGetLastError());
   if (gn_slots_used) *gn_slots_used = a.gn_slots;

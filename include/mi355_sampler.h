@@ -76,12 +76,13 @@ typedef struct mi355_debug_config {
                             *    disappears and the second conv runs prologue-free; bit 2 (with bit 0): at the 8x8 / 4x4 levels the norm of a CONCAT consumer
                             *    (unet.py:650; groups whole inside each source) is applied by the two producers, each its own channels - a skip
                             *    connection's conv then serves two sites in one epilogue; 0: gn_affine pass / finalize launch + prologue */
-  int32_t conv_pp;         /* 13: the ping-pong 3x3 kernel (conv_pp.inc.h: 8 MFMA waves in two groups that alternate LDS-read / DMA segments with MFMA
+  int32_t conv_pp;         /* 45: the ping-pong 3x3 kernel (conv_pp.inc.h: 8 MFMA waves in two groups that alternate LDS-read / DMA segments with MFMA
                             *    segments).  Bits 0-1: 1 = it takes an eligible conv when the launch has at least one tile per CU, 2 = whenever the
                             *    shape is eligible (tests), 0 = never.  Bit 2 (4): wide-geometry convs (Cout % 256 == 0) with a GroupNorm + SiLU input
                             *    prologue too (applied in LDS, in place; otherwise such convs stay on the warp-specialised kernel).  Bit 3 (8): the narrow
                             *    geometry (512 pixels x 128 channels) for Cout % 256 != 0, Cout % 128 == 0 on images at least 32 wide.  Bit 4 (16): the
-                            *    prologue form of the narrow geometry (off: it only ties the warp-specialised kernel).  The 1x1 ping-pong kernel reads bits 0-1 */
+                            *    prologue form of the narrow geometry (off: it only ties the warp-specialised kernel).  The 1x1 ping-pong kernel reads bits 0-1
+                            *    and bit 5 (32): 128-pixel x 256-channel tiles where the 256 x 256 walk gives a CU fewer than two tiles */
   int32_t conv_edge;       /* bit 0: the network's last conv (GroupNorm + SiLU -> 3x3 -> <= 4 channels, NCHW fp32) runs on the streaming kernel of
                             *    conv_edge.hip instead of the generic MFMA tile kernel; bit 1: the first conv (<= 8 real input channels -> 128,
                             *    bf16) on conv3x3_in_kernel of the same file (contraction over tap x 8 channels instead of tap x padded chunk); bit 2: that kernel

@@ -410,10 +410,12 @@ def test_pingpong_conv1x1(case, dtype, rtol, atol):
         ref = ref + res
     kw = dict(dtype=dtype, x1=x1.to(DEV) if x1 is not None else None, emb=emb.to(DEV) if emb is not None else None,
               res=res.to(DEV) if res is not None else None, res_mode=1)
-    got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=2), **kw).cpu()
     old = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=0), **kw).cpu()
-    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
-    torch.testing.assert_close(got, old, rtol=rtol, atol=atol)
+    # conv_pp = 2: the 256 x 256 / 512 x 128 tiles; 2 | 32: 128-pixel x 256-channel tiles where the wide walk has fewer than two tiles per CU (all wide cases here)
+    for mode in (2, 34):
+        got = ops.conv2d(x.to(DEV), sd["weight"], sd["bias"], debug=_lib.debug_config(conv_pp=mode), **kw).cpu()
+        torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
+        torch.testing.assert_close(got, old, rtol=rtol, atol=atol)
 
 
 def test_small_tile_conv_concat_residual_emb_fp32():
