@@ -130,8 +130,9 @@ int mi355_unet_read_tensor(const mi355_unet* net, int tensor, int gradient, floa
   const int tstate = (!gradient && (size_t)tensor < net->tensor_state_n) ? (int)net->tensor_state[tensor].load(std::memory_order_relaxed) : 0;
   if (tstate) {
     mi355_set_error(tstate == 1
-                        ? "read_tensor: the last forward did not materialise this conv output (its only reader, a GroupNorm site, ran in the conv's epilogue): "
-                          "create the handle with debug.gn_epilogue = 0 to inspect it"
+                        ? "read_tensor: the last forward did not materialise this tensor (a conv output whose only reader, a GroupNorm site, ran in the conv's "
+                          "epilogue; a 1x1 skip conv that rode in the next 3x3 conv; the packed network input the first conv read from the caller's tensor): "
+                          "create the handle with debug.gn_epilogue = 0, conv_small = 7, conv_edge = 3 to inspect it"
                         : "read_tensor: the last forward normalised this conv output in place (16x16 level: it holds silu(GroupNorm(.)), not the conv's result): "
                           "create the handle with debug.gn_epilogue = 0 (or 1) to inspect it");
     return MI355_ERR_UNSUPPORTED;

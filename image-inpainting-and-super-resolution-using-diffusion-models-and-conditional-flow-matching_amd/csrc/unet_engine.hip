@@ -623,7 +623,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
     const int C1 = op.src1 >= 0 ? net->tensors[op.src1].C : 0;
     if (op.kind == OP_GN && gn_done[(size_t)(&op - net->ops.data())]) {
       rc = 0;   // applied by the producing conv's epilogue
-      r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W; r.bytes = 0;
+      r.kind = MI355_OP_GN; r.cin = s0.C + C1; r.h = s0.H; r.w = s0.W; r.bytes = 0; r.tile_m = r.tile_n = -1;   // (tile -1: nothing was launched for this op)
     } else if (op.kind == OP_GN && op.fin_ok && op.dst < 0 && gn_slots[op.src0] > 0 && (op.src1 < 0 || gn_slots[op.src1] > 0)) {
       GnFinDesc g; g.stats0 = SP(op.src0); g.slots0 = gn_slots[op.src0]; g.C0 = s0.C;
       if (op.src1 >= 0) { g.stats1 = SP(op.src1); g.slots1 = gn_slots[op.src1]; g.C1 = C1; }
@@ -664,7 +664,7 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
       gn_done[(size_t)(&op - net->ops.data())] = 1;   // (counts as a launch that did not happen)
       if (op.dst >= 0 && (size_t)op.dst < net->tensor_state_n) net->tensor_state[op.dst].store((char)1, std::memory_order_relaxed);
       rc = 0;
-      r.kind = MI355_OP_CONV; r.ks = op.ks; r.cin = s0.C + C1; r.cout = op.Cout; r.h = s0.H; r.w = s0.W;
+      r.kind = MI355_OP_CONV; r.ks = op.ks; r.cin = s0.C + C1; r.cout = op.Cout; r.h = s0.H; r.w = s0.W; r.tile_m = r.tile_n = -1;
     } else if (op.kind == OP_CONV) {
       ConvDesc c; c.dtype = dtype; c.src0 = TP(op.src0); c.C0 = s0.C; c.src1 = TP(op.src1); c.C1 = C1;
       c.N = B; c.Hs = s0.H; c.Ws = s0.W; c.mode = op.mode; c.ks = op.ks; c.wsplit = net->wsplit;
@@ -761,6 +761,10 @@ int unet_forward(const mi355_unet* net, const float* x, int Cx, const float* con
         r.kind = MI355_OP_CONV; r.ks = op.ks; r.cin = cin; r.cout = op.Cout; r.h = cg.Ho; r.w = cg.Wo; r.tile_m = cg.BM; r.tile_n = cg.BN;
         r.flops = 2.0 * B * cg.Ho * cg.Wo * (double)op.Cout * cin * op.ks * op.ks;
         r.bytes = ((double)B * s0.H * s0.W * cin + (double)B * cg.Ho * cg.Wo * op.Cout) * esz + (double)op.Cout * cin * op.ks * op.ks * esz;
+        if (skip_fused[oi]) {   // the ResBlock's 1x1 skip conv this launch carried
+          r.flops += 2.0 * B * cg.Ho * cg.Wo * (double)op.Cout * (c.skip_C0 + c.skip_C1);
+          r.bytes += ((double)B * cg.Ho * cg.Wo + (double)op.Cout) * (c.skip_C0 + c.skip_C1) * esz;
+        }
       }
     } else if (op.kind == OP_ATTN) {
       AttnDesc a; a.dtype = dtype; a.qkv = TP(op.src0); a.out = TP(op.dst); a.N = B; a.T = s0.H * s0.W;

@@ -194,7 +194,8 @@ int mi355_unet_get_stats(const mi355_unet* net, int batch, mi355_unet_stats* out
 #define MI355_OP_RESAMPLE 4
 typedef struct mi355_op_profile {
   int32_t kind, ks, cin, cout, h, w; /* conv: kernel size, in/out channels, OUTPUT height/width */
-  int32_t tile_m, tile_n;            /* conv: workgroup tile */
+  int32_t tile_m, tile_n;            /* conv: workgroup tile; -1, -1: the plan op launched nothing in this forward (a GroupNorm site its producers applied, a 1x1 skip conv
+                                      * that rode in the next 3x3 conv): its ms is the event pair's own cost */
   float ms;
   double flops; /* algorithmic 2*MAC */
   double bytes; /* algorithmic bytes: activations in + out (+ weights once) */
