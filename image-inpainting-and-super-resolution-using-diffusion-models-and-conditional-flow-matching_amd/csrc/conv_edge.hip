@@ -157,6 +157,19 @@ __global__ void __launch_bounds__(256) conv3x3_out_kernel(OutArgs p) {
   // ---- contraction: wave w owns tile rows 2 w, 2 w + 1; D rows = output channels (4 lq + j), columns = the 16 pixels of a row; a chunk's
   //      27 fragments are read before its 18 MFMAs ----
   const int lr = lane & 15, lq = lane >> 4;
+  // fused Euler update: this lane's state values are requested now and used after the contraction (no other workgroup touches these pixels)
+  float xs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (p.axpy_x && lq == 0) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int y = y0 + 2 * wave + mi, x = x0 + lr;
+      if (y < p.H && x < p.W) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < p.Cout) xs[mi][j] = p.axpy_x[(((size_t)n0 * p.Cout + j) * p.H + y) * p.W + x];
+      }
+    }
+  }
   const int co = lr < p.Cout ? lr : 0;       // lanes of unused accumulator rows read row 0 (their results are never stored)
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   int abase[3];
@@ -192,7 +205,7 @@ __global__ void __launch_bounds__(256) conv3x3_out_kernel(OutArgs p) {
             const float v = acc[mi][j] + (p.bias ? p.bias[j] : 0.f);
             if (p.axpy_x) {
 #pragma clang fp contract(off)   // (the expression of steps.hip euler_step_launch, rounded the same way)
-              p.axpy_x[oi] = p.axpy_x[oi] + p.axpy_scale * v;
+              p.axpy_x[oi] = xs[mi][j] + p.axpy_scale * v;
             } else p.out[oi] = v;
           }
       }
