@@ -30,7 +30,7 @@ const mi355_debug_config& mi355_default_debug() {
 
 extern "C" {
 
-int mi355_version(void) { return 103; }
+int mi355_version(void) { return 104; }
 void mi355_debug_defaults(mi355_debug_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
@@ -411,10 +411,40 @@ int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw) {
   return (int64_t)(2 * al256((size_t)batch * hw * 4 * c * 4) + al256(c * c * 9 * 4 * 2) + 4 * al256((size_t)batch * c * 4) + (1 << 20));
 }
 
+namespace {
+// device scratch of mi355_conv2d_ex's extras (a test op: plain hipMalloc, freed when the call returns)
+struct ExScratch {
+  std::vector<void*> ptrs;
+  ~ExScratch() { for (void* q : ptrs) (void)hipFree(q); }
+  void* get(size_t bytes) { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 256) != hipSuccess) return nullptr; ptrs.push_back(q); return q; }
+};
+}  // namespace
+
+static int conv2d_impl(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
+                       int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
+                       const float* emb, const float* res, int res_mode, int dtype, const mi355_debug_config* debug, void* workspace,
+                       int64_t workspace_bytes, void* stream, mi355_conv_extras* ex);
+
 int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
                  int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
                  const float* emb, const float* res, int res_mode, int dtype, const mi355_debug_config* debug, void* workspace,
                  int64_t workspace_bytes, void* stream) {
+  return conv2d_impl(x, x1, cin1, w_host, bias_host, y, batch, cin, h, w, cout, ksize, stride, resample, gn_gamma, gn_beta, gn_silu, emb, res, res_mode,
+                     dtype, debug, workspace, workspace_bytes, stream, nullptr);
+}
+int mi355_conv2d_ex(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
+                    int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
+                    const float* emb, const float* res, int res_mode, int dtype, const mi355_debug_config* debug, void* workspace,
+                    int64_t workspace_bytes, void* stream, mi355_conv_extras* extras) {
+  MI355_REQUIRE(extras, -1, "conv2d_ex: null extras");
+  return conv2d_impl(x, x1, cin1, w_host, bias_host, y, batch, cin, h, w, cout, ksize, stride, resample, gn_gamma, gn_beta, gn_silu, emb, res, res_mode,
+                     dtype, debug, workspace, workspace_bytes, stream, extras);
+}
+
+static int conv2d_impl(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
+                       int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
+                       const float* emb, const float* res, int res_mode, int dtype, const mi355_debug_config* debug, void* workspace,
+                       int64_t workspace_bytes, void* stream, mi355_conv_extras* ex) {
   const mi355_debug_config& K = debug ? *debug : mi355_default_debug();
   MI355_REQUIRE(x && w_host && y && workspace, -1, "conv2d: null argument");
   MI355_REQUIRE(dtype == MI355_F32 || dtype == MI355_BF16 || dtype == MI355_BF16X2 || dtype == MI355_F16, -1, "conv2d: bad dtype");
@@ -489,7 +519,61 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
   p += 65536;
   d.dbg = p;
 #endif
-  if ((rc = conv_launch(d, s))) return rc;
+  // ---- extras (mi355_conv2d_ex): the small-level kernel's fused forms, as the engine's walker asks for them ----
+  ExScratch xs;
+  void* act_dev[2] = {nullptr, nullptr};
+  std::vector<char> packed_f; std::vector<float> bias_f;
+  int act_done = 0;
+  if (ex) {
+    ex->act_done = 0; ex->skip_done = 0;
+    MI355_REQUIRE(nhwc && !pool, -4, "conv2d_ex: extras need an NHWC output and no pooling");
+    if (ex->skip_x0) {
+      MI355_REQUIRE(ksize == 3 && stride == 1 && !resample && !x1 && !res && !wsplit && ex->skip_w_host && ex->skip_c0 > 0, -1, "conv2d_ex: the fused skip conv goes with a plain 3x3 conv of one source");
+      MI355_REQUIRE((ex->skip_x1 != nullptr) == (ex->skip_c1 > 0), -1, "conv2d_ex: skip_x1 and skip_c1 go together");
+      const int cs = ex->skip_c0 + ex->skip_c1;
+      void* k0 = xs.get((size_t)batch * h * w * ex->skip_c0 * esz);
+      void* k1 = ex->skip_x1 ? xs.get((size_t)batch * h * w * ex->skip_c1 * esz) : nullptr;
+      const size_t fb = conv_packed_weight_bytes_skip(dtype, cout, ctot, cs);
+      void* wf = xs.get(fb);
+      MI355_REQUIRE(k0 && wf && (!ex->skip_x1 || k1), -2, "conv2d_ex: out of device memory");
+      if ((rc = pack_nhwc_launch(dtype, ex->skip_x0, ex->skip_c0, nullptr, 0, batch, h * w, ex->skip_c0, k0, s))) return rc;
+      if (k1 && (rc = pack_nhwc_launch(dtype, ex->skip_x1, ex->skip_c1, nullptr, 0, batch, h * w, ex->skip_c1, k1, s))) return rc;
+      packed_f.resize(fb);
+      conv_pack_weights_skip(dtype, w_host, ex->skip_w_host, cout, ctot, cs, packed_f.data());
+      MI355_CHECK_HIP(hipMemcpyAsync(wf, packed_f.data(), fb, hipMemcpyHostToDevice, s));
+      bias_f.assign((size_t)cout, 0.f);
+      for (int i = 0; i < cout; ++i) bias_f[i] = (bias_host ? bias_host[i] : 0.f) + (ex->skip_bias_host ? ex->skip_bias_host[i] : 0.f);
+      MI355_CHECK_HIP(hipMemcpyAsync(bdev, bias_f.data(), (size_t)cout * 4, hipMemcpyHostToDevice, s));
+      d.w = wf; d.bias = bdev;
+      d.skip_src0 = k0; d.skip_C0 = ex->skip_c0; d.skip_src1 = k1; d.skip_C1 = ex->skip_c1;
+      if (conv_fused_skip_ok(d) != 0) { mi355_set_error("conv2d_ex: this launch cannot carry the fused skip conv (shape, batch or knobs)"); return MI355_ERR_UNSUPPORTED; }
+      ex->skip_done = 1;
+    }
+    for (int k = 0; k < 2; ++k) {
+      if (!ex->act_out[k]) continue;
+      MI355_REQUIRE(k == 0 || ex->act_out[0], -1, "conv2d_ex: site 1 without site 0");
+      MI355_REQUIRE(ex->act_gamma[k] && ex->act_beta[k] && ex->act_ctotal[k] % 32 == 0 && ex->act_coff[k] >= 0 && ex->act_coff[k] + cout <= ex->act_ctotal[k], -1, "conv2d_ex: bad GroupNorm site");
+      const size_t ab = (size_t)batch * g.Ho * g.Wo * ex->act_ctotal[k] * esz;
+      act_dev[k] = xs.get(ab);
+      MI355_REQUIRE(act_dev[k], -2, "conv2d_ex: out of device memory");
+      MI355_CHECK_HIP(hipMemsetAsync(act_dev[k], 0, ab, s));
+    }
+    if (act_dev[0]) {
+      d.act_out = act_dev[0]; d.act_gamma = ex->act_gamma[0] + ex->act_coff[0]; d.act_beta = ex->act_beta[0] + ex->act_coff[0];
+      d.act_silu = ex->act_silu[0]; d.act_stride = ex->act_ctotal[0]; d.act_coff = ex->act_coff[0]; d.act_cpg = ex->act_ctotal[0] / 32; d.act_raw = 1;
+      if (ex->act_film) { d.act_film = ex->act_film; d.act_film_stride = 2 * cout; }
+    }
+    if (act_dev[1]) {
+      d.act2_out = act_dev[1]; d.act2_gamma = ex->act_gamma[1] + ex->act_coff[1]; d.act2_beta = ex->act_beta[1] + ex->act_coff[1];
+      d.act2_silu = ex->act_silu[1]; d.act2_stride = ex->act_ctotal[1]; d.act2_coff = ex->act_coff[1]; d.act2_cpg = ex->act_ctotal[1] / 32;
+    }
+  }
+  if ((rc = conv_launch(d, s, nullptr, ex ? &act_done : nullptr))) return rc;
+  if (ex) {
+    ex->act_done = act_done;
+    for (int k = 0; k < 2; ++k)
+      if (act_dev[k] && (act_done & (1 << k)) && (rc = unpack_nchw_launch(dtype, act_dev[k], batch, g.Ho * g.Wo, ex->act_ctotal[k], ex->act_out[k], s))) return rc;
+  }
   if (K.conv_time_reps > 0) {   // diagnostic: average duration of the conv launch alone
     const int reps = K.conv_time_reps;
     hipEvent_t e0, e1;

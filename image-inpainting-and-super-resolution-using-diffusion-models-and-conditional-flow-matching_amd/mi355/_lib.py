@@ -65,6 +65,15 @@ class UNetConfigC(C.Structure):
     ]
 
 
+class ConvExtrasC(C.Structure):
+    """mi355_conv_extras (include/mi355_sampler.h): the fused forms of the small-level conv, for mi355_conv2d_ex."""
+    _fields_ = [("skip_x0", C.c_void_p), ("skip_x1", C.c_void_p), ("skip_c0", C.c_int32), ("skip_c1", C.c_int32),
+                ("skip_w_host", C.c_void_p), ("skip_bias_host", C.c_void_p),
+                ("act_out", C.c_void_p * 2), ("act_gamma", C.c_void_p * 2), ("act_beta", C.c_void_p * 2),
+                ("act_ctotal", C.c_int32 * 2), ("act_coff", C.c_int32 * 2), ("act_silu", C.c_int32 * 2),
+                ("act_film", C.c_void_p), ("act_done", C.c_int32), ("skip_done", C.c_int32)]
+
+
 class UNetStatsC(C.Structure):
     _fields_ = [("launches", C.c_int64), ("conv_flops", C.c_double), ("attn_flops", C.c_double),
                 ("act_bytes", C.c_double), ("weight_bytes", C.c_double)]
@@ -141,6 +150,8 @@ SIGNATURES = {
     "mi355_box_probe": (_I, [_I, _VP, _I64, _VP, _FP, _FP, _FP]),
     "mi355_conv2d": (_I, [_VP, _VP, _I, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _I, C.POINTER(DebugConfigC), _VP,
                           _I64, _VP]),
+    "mi355_conv2d_ex": (_I, [_VP, _VP, _I, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _I, C.POINTER(DebugConfigC), _VP,
+                             _I64, _VP, C.POINTER(ConvExtrasC)]),
     "mi355_qkv_attention": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I64, _VP]),
 }
 

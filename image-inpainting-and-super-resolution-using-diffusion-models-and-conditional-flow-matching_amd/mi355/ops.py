@@ -233,6 +233,47 @@ class Ops:
               "mi355_conv2d")
         return y
 
+    def conv2d_ex(self, x, weight, bias, dtype=_lib.MI355_F32, skip=None, sites=(), film=None, debug=None):
+        """The 3x3 conv of the 8x8 / 4x4 levels with its fused forms (mi355_conv2d_ex): skip = (xs0, xs1 or None, w1 [Co, c0 + c1, 1, 1], b1) is a
+        1x1 conv of cat(xs0, xs1) accumulated into the same output; sites = up to two dicts (ctotal, coff, gamma, beta, silu): GroupNorm32 (+SiLU)
+        of the output as channels coff.. of a ctotal-channel tensor, written by the epilogue; film [B, 2 Co] on site 0.  Returns
+        (y, [act or None per site], skip_done)."""
+        B, Cin, H, W = x.shape
+        Co, Ci, k, _ = weight.shape
+        assert Ci == Cin and k == 3 and len(sites) <= 2
+        y = torch.empty(B, Co, H, W, device=x.device, dtype=torch.float32)
+        L = _lib.lib()
+        wsb = L.mi355_op_workspace_bytes(B, max(Ci, Co), H * W)
+        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        b = bias.detach().to("cpu", torch.float32).contiguous() if bias is not None else None
+        fp = C.POINTER(C.c_float)
+        ex = _lib.ConvExtrasC()
+        keep = []
+        if skip is not None:
+            xs0, xs1, w1, b1 = skip
+            w1c = w1.detach().to("cpu", torch.float32).reshape(Co, -1).contiguous()
+            b1c = b1.detach().to("cpu", torch.float32).contiguous() if b1 is not None else None
+            keep += [w1c, b1c]
+            ex.skip_x0 = _req(xs0, "skip_x0"); ex.skip_c0 = xs0.shape[1]
+            if xs1 is not None:
+                ex.skip_x1 = _req(xs1, "skip_x1"); ex.skip_c1 = xs1.shape[1]
+            ex.skip_w_host = w1c.data_ptr()
+            ex.skip_bias_host = b1c.data_ptr() if b1c is not None else None
+        acts = []
+        for i, st in enumerate(sites):
+            a = torch.full((B, st["ctotal"], H, W), float("nan"), device=x.device, dtype=torch.float32)
+            acts.append(a)
+            ex.act_out[i] = _req(a, "act_out"); ex.act_gamma[i] = _req(st["gamma"], "gamma"); ex.act_beta[i] = _req(st["beta"], "beta")
+            ex.act_ctotal[i] = st["ctotal"]; ex.act_coff[i] = st["coff"]; ex.act_silu[i] = int(st.get("silu", True))
+        if film is not None:
+            ex.act_film = _req(film, "film")
+        check(L.mi355_conv2d_ex(_req(x, "x"), None, 0, C.cast(w.data_ptr(), fp), C.cast(b.data_ptr(), fp) if b is not None else None, _req(y, "y"),
+                                B, Cin, H, W, Co, 3, 1, 0, None, None, 0, None, None, 1, dtype,
+                                C.byref(debug if debug is not None else _lib.debug_config()), C.c_void_p(ws.data_ptr()), wsb, _stream(), C.byref(ex)),
+              "mi355_conv2d_ex")
+        return y, [a if (ex.act_done >> i) & 1 else None for i, a in enumerate(acts)], bool(ex.skip_done)
+
     def qkv_attention(self, qkv, heads, new_order=False, dtype=_lib.MI355_F32):
         B, width, T = qkv.shape
         ch = width // (3 * heads)

@@ -42,7 +42,9 @@ extern "C" {
                      * precision mode (UNetModel(use_fp16=True) runs its torso in float16, AD/image_diffusion/unet.py:559-563): bf16's speed, three more
                      * mantissa bits on every stored activation and weight; values beyond +-65504 overflow to inf as they do in the reference */
 
-/* ABI version = 100 * major + minor.  The minor number counts additive changes; 103 (round 5): conv_pp became a bit mask (bits 2, 3, 4: the
+/* ABI version = 100 * major + minor.  The minor number counts additive changes; 104 (round 5, later): mi355_conv2d_ex (the small-level conv's fused forms as a
+ * test op), gn_epilogue bit 2, conv_small bit 3, conv_edge bits 2-3, conv_pp bit 5, mi355_op_profile::tile_m = -1 for plan ops that launched nothing.
+ * 103 (round 5): conv_pp became a bit mask (bits 2, 3, 4: the
  * prologue and narrow forms of the ping-pong kernel), mi355_box_probe, MI355_BF16X2 and MI355_F16 added.  102 (round 4): mi355_debug_config gained conv_pp and
  * conv_edge (carved out of its reserved tail: the struct's size is unchanged), attn_fused became a bit mask, mi355_unet_read_tensor
  * returns MI355_ERR_UNSUPPORTED for a tensor the plan did not materialise as stored.  Callers that fill a mi355_debug_config must start
@@ -366,6 +368,27 @@ int mi355_conv2d(const float* x, const float* x1, int cin1, const float* w_host,
                  int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
                  const float* emb, const float* res, int res_mode, int dtype, const mi355_debug_config* debug, void* workspace,
                  int64_t workspace_bytes, void* stream);
+/* The same op with the fused forms the engine asks of the 8x8 / 4x4-level conv (csrc/conv_small.inc.h), for op-level parity tests:
+ *  - a ResBlock's 1x1 skip_connection (unet.py:312-317, 351) over cat(skip_x0, skip_x1) accumulated into the same output as centre-tap K chunks
+ *    (skip_w_host [Co, c0 + c1], skip_bias_host [Co]: HOST pointers; needs ksize 3, stride 1, one source, no residual).  MI355_ERR_UNSUPPORTED
+ *    if the launch cannot carry it;
+ *  - up to two GroupNorm32 (+ SiLU) sites applied in the epilogue (unet.py:196-212, 650; nn.py:87-94): site k normalises this conv's Co output
+ *    channels as channels act_coff[k] .. of a tensor of act_ctotal[k] channels (groups of act_ctotal[k] / 32; gamma / beta [act_ctotal[k]],
+ *    device) and writes them into act_out[k] ([B, act_ctotal[k], Ho, Wo] fp32, device; the other channels are written as zeros); FiLM
+ *    (act_film [B, 2 Co] = scale | shift, unet.py:343-347) on site 0 only.  act_done reports which sites the launch applied (bit k); a
+ *    site it did not apply leaves its act_out untouched.  y is the conv's own output as in mi355_conv2d. */
+typedef struct mi355_conv_extras {
+  const float* skip_x0; const float* skip_x1; int32_t skip_c0, skip_c1;
+  const float* skip_w_host; const float* skip_bias_host;
+  float* act_out[2]; const float* act_gamma[2]; const float* act_beta[2];
+  int32_t act_ctotal[2], act_coff[2], act_silu[2];
+  const float* act_film;
+  int32_t act_done, skip_done;   /* out */
+} mi355_conv_extras;
+int mi355_conv2d_ex(const float* x, const float* x1, int cin1, const float* w_host, const float* bias_host, float* y, int batch, int cin,
+                    int h, int w, int cout, int ksize, int stride, int resample, const float* gn_gamma, const float* gn_beta, int gn_silu,
+                    const float* emb, const float* res, int res_mode, int dtype, const mi355_debug_config* debug, void* workspace,
+                    int64_t workspace_bytes, void* stream, mi355_conv_extras* extras);
 /* QKVAttentionLegacy / QKVAttention (unet.py:424-487): qkv [B, 3*H*ch, T] -> out [B, H*ch, T] */
 int mi355_qkv_attention(const float* qkv, float* out, int batch, int heads, int head_channels, int length, int new_order,
                         int dtype, void* workspace, int64_t workspace_bytes, void* stream);

@@ -418,6 +418,70 @@ def test_pingpong_conv1x1(case, dtype, rtol, atol):
         torch.testing.assert_close(got, old, rtol=rtol, atol=atol)
 
 
+SMALL_FUSED_CASES = [
+    # B, C, H, Co, skip (c0, c1) or None, sites [(ctotal, coff)], film
+    (256, 256, 8, 256, (256, 256), [(512, 0)], False),       # up-path conv2 at 8x8: skip conv over the concat + h's half of the next concat norm (16 ch / group)
+    (256, 256, 8, 256, None, [(256, 0), (512, 256)], False), # a skip connection's producer: its own next norm (8 / group) and its half of the up path's (16 / group)
+    (256, 256, 4, 256, (256, 256), [(512, 0)], False),       # the same block at 4x4: four K-sharing waves, skip planes beside the main patch
+    (64, 256, 4, 256, (256, 256), [(256, 0)], True),         # FiLM site + skip conv, a quarter of the chip's workgroups
+    (8, 128, 8, 128, (128, 0), [(128, 0)], False),           # 128 channels: 4 per group, one skip source, K-sharing 8x8 form (no wave-local statistics: site not applied)
+    (1100, 256, 4, 256, (128, 128), [(256, 0), (512, 0)], False),   # 4x4 without K sharing (four images per wave), ragged last tile, two sites
+    (258, 128, 8, 128, (256, 128), [(256, 128)], False),     # 384 skip channels on a 128-channel conv, its output as the SECOND source of a 256-channel norm
+]
+
+
+@pytest.mark.parametrize("case", SMALL_FUSED_CASES)
+@pytest.mark.parametrize("dtype,tol", [(_lib.MI355_F32, 1e-4), (_lib.MI355_BF16, 3e-2), (_lib.MI355_F16, 4e-3)])
+def test_small_level_conv_fused_forms(case, dtype, tol):
+    """conv3x3_small_kernel's fused forms through the C ABI (mi355_conv2d_ex) against PyTorch: the ResBlock's 1x1 skip_connection accumulated
+    into the block's second conv (unet.py:312-317, 351: skip_connection(x) + h) and the GroupNorm32 (+SiLU, +FiLM) sites of the output applied
+    by the epilogue, a site being this conv's channels inside a wider (concat) tensor (unet.py:196-212, 343-347, 650; nn.py:87-94).
+    Reference: F.conv2d + F.conv2d(cat) ; F.group_norm over the conv's own channels in groups of ctotal / 32 with the slice of (gamma, beta)."""
+    from mi355.ops import default_ops as ops
+
+    B, C, H, Co, skip, sites, film = case
+    seed = 9900 + (B * 7 + C + H * 13 + Co + len(sites)) % 300
+    x = randn(seed, B, C, H, H) * 0.9
+    sd = synth_state_dict({"weight": (Co, C, 3, 3), "bias": (Co,)}, seed + 1)
+    ref = F.conv2d(x, sd["weight"], sd["bias"], padding=1)
+    sk = None
+    if skip:
+        c0, c1 = skip
+        xs0 = randn(seed + 2, B, c0, H, H) * 1.1 + 0.1
+        xs1 = randn(seed + 3, B, c1, H, H) * 0.6 - 0.2 if c1 else None
+        sw = synth_state_dict({"weight": (Co, c0 + c1, 1, 1), "bias": (Co,)}, seed + 4)
+        ref = ref + F.conv2d(xs0 if xs1 is None else torch.cat((xs0, xs1), 1), sw["weight"], sw["bias"])
+        sk = (xs0.to(DEV), xs1.to(DEV) if xs1 is not None else None, sw["weight"], sw["bias"])
+    fl = (randn(seed + 5, B, 2 * Co) * 0.3).to(DEV) if film else None
+    sts, refs = [], []
+    for i, (ct, co) in enumerate(sites):
+        g = synth_state_dict({"weight": (ct,), "bias": (ct,)}, seed + 10 + i)
+        gam, bet = g["weight"] + 1.0, g["bias"]
+        sts.append(dict(ctotal=ct, coff=co, gamma=gam.to(DEV), beta=bet.to(DEV), silu=True))
+        r = F.group_norm(ref, Co // (ct // 32), gam[co:co + Co], bet[co:co + Co], eps=1e-5)
+        if film and i == 0:
+            f = fl.cpu()
+            r = r * (1 + f[:, :Co, None, None]) + f[:, Co:, None, None]
+        refs.append(F.silu(r))
+    y, acts, skip_done = ops.conv2d_ex(x.to(DEV), sd["weight"], sd["bias"], dtype=dtype, skip=sk, sites=sts, film=fl)
+    scale = ref.abs().max().item()
+    assert skip_done == (skip is not None)
+    assert (y.cpu() - ref).abs().max().item() < tol * scale
+    # an 8x8 image whose channels are split over K-sharing waves (fewer than four 64-channel waves along N: Co % 256 != 0, or too few tiles
+    # for the chip) has no wave-local statistics: the launch reports the site as not applied and the walker keeps the pass
+    wave_local = not (H == 8 and (Co % 256 != 0 or B * (Co // 256) < 256))
+    for i, (ct, co) in enumerate(sites):
+        cpg = ct // 32
+        if cpg in (4, 8, 16) and wave_local:
+            assert acts[i] is not None, (i, ct, co)
+            a = acts[i].cpu()
+            assert (a[:, co:co + Co] - refs[i]).abs().max().item() < max(tol, 2e-4) * max(1.0, refs[i].abs().max().item())
+            rest = torch.cat((a[:, :co], a[:, co + Co:]), 1)
+            assert rest.numel() == 0 or rest.abs().max().item() == 0.0
+        else:
+            assert acts[i] is None
+
+
 def test_small_tile_conv_concat_residual_emb_fp32():
     """The same epilogue / two-source paths on the plain (non-persistent) kernels: small batches, 8x8 multi-image tiles, 1x1."""
     from mi355.ops import default_ops as ops
