@@ -30,7 +30,7 @@ const mi355_debug_config& mi355_default_debug() {
 
 extern "C" {
 
-int mi355_version(void) { return 104; }
+int mi355_version(void) { return 105; }
 void mi355_debug_defaults(mi355_debug_config* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
@@ -79,7 +79,9 @@ int64_t mi355_unet_workspace_bytes(const mi355_unet* net, int batch) {
   if (!net || batch <= 0) { mi355_set_error("bad argument"); return -1; }
   // + sampler scratch: t[B], eps/v [B,Cout,H,W], none_like [B,Cin,H,W], and the per-step time-embedding table of the sampler loops
   const size_t hw = (size_t)net->cfg.image_size * net->cfg.image_size;
-  const size_t scratch = al256((size_t)batch * 4) + 2 * al256((size_t)batch * 32 * hw * 4) + emb_table_bytes(net);
+  // (+ the graph form's resident state [B,Cout,H,W], mi355_debug_config::sampler_graph)
+  const size_t scratch = al256((size_t)batch * 4) + 2 * al256((size_t)batch * 32 * hw * 4) + emb_table_bytes(net) +
+                         al256((size_t)batch * net->cfg.out_channels * hw * 4);
   return unet_workspace_bytes(net, batch) + (int64_t)scratch;
 }
 
@@ -188,7 +190,7 @@ int mi355_unet_profile(mi355_unet* net, const float* x, int x_channels, const fl
 
 // ---- sampler loops --------------------------------------------------------------------------------
 
-struct Scratch { float* t; float* v; float* none; float* tsteps; float* embtab; char* unet_ws; int64_t unet_bytes; };
+struct Scratch { float* t; float* v; float* none; float* tsteps; float* embtab; float* xstate; char* unet_ws; int64_t unet_bytes; };
 // every image of a sampler step shares the step time: the engine computes ONE embedding row (stride-0 broadcast)
 static UnetRun uniform_t_run() { UnetRun r; r.t_uniform = 1; return r; }
 // table[k] = emb_layers outputs for step time t_host[k] (k < n <= EMB_TABLE_STEPS); returns the table or null (per-step path)
@@ -212,8 +214,73 @@ static int carve(mi355_unet* net, int B, void* workspace, int64_t workspace_byte
   sc.none = reinterpret_cast<float*>(p); p += al256((size_t)B * 32 * hw * 4);
   sc.tsteps = reinterpret_cast<float*>(p); p += al256((size_t)EMB_TABLE_STEPS * 4);
   sc.embtab = reinterpret_cast<float*>(p); p += al256((size_t)EMB_TABLE_STEPS * ((size_t)net->emb_total + 9 * (size_t)net->cfg.model_channels) * 4);
+  sc.xstate = reinterpret_cast<float*>(p); p += al256((size_t)B * net->cfg.out_channels * hw * 4);
   sc.unet_ws = p;
   sc.unet_bytes = workspace_bytes - (p - reinterpret_cast<char*>(workspace));
+  return 0;
+}
+
+// The loop proper: every launch of every step on stream s (the caller's stream, or the handle's capture stream while a graph is recorded).
+static int cfm_euler_loop(mi355_unet* net, const Scratch& sc, float* x, int x_channels, const float* cond, int cond_channels, float* cdrift,
+                          const float* t_span_host, int n_t, const float* emb_table, float* traj, int batch, int64_t n, int64_t nc, hipStream_t s) {
+  UnetRun run = uniform_t_run();
+  for (int k = 0; k + 1 < n_t; ++k) {
+    const float t = t_span_host[k], dt = t_span_host[k + 1] - t_span_host[k];
+    int rc;
+    if (emb_table) run.emb_row = emb_table + (size_t)k * net->emb_total;
+    else if ((rc = fill_launch(sc.t, t, batch, s))) return rc;
+    run.euler_x = x; run.euler_dt = dt;   // x += dt * v: in the last conv's epilogue, or as a launch of unet_forward's own behind it
+    if ((rc = unet_forward(net, x, x_channels, cond, cond_channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s, run))) return rc;
+    if (cdrift && (rc = euler_step_launch(cdrift, cdrift, dt, nc, s))) return rc;
+    if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * n, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+// knobs.sampler_graph: the loop as ONE graph launch.  The graph works on the workspace's resident state (sc.xstate) so that it does not depend on
+// the caller's x / u8 pointers (a fresh tensor per call is the normal use); it does depend on the workspace, the batch, the schedule (dt is a kernel
+// argument, the embedding rows are table addresses) and the condition pointer: those are its key.  The embedding table is rebuilt on every call,
+// outside the graph (the workspace is the caller's: another sampler may have used it in between).
+static int cfm_euler_graph(mi355_unet* net, const Scratch& sc, float* x, int x_channels, const float* cond, int cond_channels, const float* t_span_host,
+                           int n_t, const float* emb_table, int batch, int64_t n, void* workspace, hipStream_t s) {
+  uint64_t h = 1469598103934665603ull;
+  for (int k = 0; k < n_t; ++k) { uint32_t b; std::memcpy(&b, &t_span_host[k], 4); h = (h ^ b) * 1099511628211ull; }
+  const uint64_t key[8] = {(uint64_t)reinterpret_cast<uintptr_t>(workspace), (uint64_t)batch, (uint64_t)n_t, h, (uint64_t)reinterpret_cast<uintptr_t>(cond),
+                           (uint64_t)cond_channels, (uint64_t)x_channels, (uint64_t)reinterpret_cast<uintptr_t>(emb_table)};
+  std::lock_guard<std::mutex> lock(net->graph_mu);
+  mi355_unet::SamplerGraph* g = nullptr;
+  for (auto& e : net->graphs) if (e.exec && std::memcmp(e.key, key, sizeof(key)) == 0) { g = &e; break; }
+  if (!g) {
+    if (!net->capture_stream) MI355_CHECK_HIP(hipStreamCreateWithFlags(&net->capture_stream, hipStreamNonBlocking));
+    hipStream_t cs = net->capture_stream;
+    MI355_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    int rc = cfm_euler_loop(net, sc, sc.xstate, x_channels, cond, cond_channels, nullptr, t_span_host, n_t, emb_table, nullptr, batch, n, 0, cs);
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(cs, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) { mi355_set_error(std::string("cfm_euler_sample: graph capture failed: ") + hipGetErrorString(e)); return -3; }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { mi355_set_error(std::string("cfm_euler_sample: graph instantiation failed: ") + hipGetErrorString(e)); return -3; }
+    constexpr size_t CAP = 4;
+    if (net->graphs.size() < CAP) { net->graphs.emplace_back(); g = &net->graphs.back(); }
+    else {
+      g = &net->graphs[0];
+      for (auto& c : net->graphs) if (c.stamp < g->stamp) g = &c;
+      // the replaced graph may still be running on a stream of the caller's: wait for the device before its nodes are freed (rare: a fifth key)
+      (void)hipDeviceSynchronize();
+      (void)hipGraphExecDestroy(g->exec);
+    }
+    std::memcpy(g->key, key, sizeof(key));
+    g->exec = exec;
+    g->launches = net->last_launches;
+  }
+  g->stamp = ++net->graph_clock;
+  MI355_CHECK_HIP(hipMemcpyAsync(sc.xstate, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  MI355_CHECK_HIP(hipGraphLaunch(g->exec, s));
+  MI355_CHECK_HIP(hipMemcpyAsync(x, sc.xstate, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  net->last_launches = g->launches;
   return 0;
 }
 
@@ -224,7 +291,6 @@ int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const floa
   MI355_REQUIRE(x_channels == net->cfg.out_channels, -2, "cfm_euler_sample: the vector field must have the state's channel count");
   Scratch sc;
   if (int rc = carve(net, batch, workspace, workspace_bytes, sc)) return rc;
-  UnetRun run = uniform_t_run();
   hipStream_t s = S(stream);
   const float* emb_table = nullptr;
   if (int rc = make_emb_table(net, sc, t_span_host, n_t - 1, s, &emb_table)) return rc;
@@ -241,16 +307,12 @@ int mi355_cfm_euler_sample(mi355_unet* net, float* x, int x_channels, const floa
     MI355_CHECK_HIP(hipMemcpyAsync(cdrift, cond, (size_t)nc * 4, hipMemcpyDeviceToDevice, s));
     cond = cdrift;
   }
-  for (int k = 0; k + 1 < n_t; ++k) {
-    const float t = t_span_host[k], dt = t_span_host[k + 1] - t_span_host[k];
-    int rc;
-    if (emb_table) run.emb_row = emb_table + (size_t)k * net->emb_total;
-    else if ((rc = fill_launch(sc.t, t, batch, s))) return rc;
-    run.euler_x = x; run.euler_dt = dt;   // x += dt * v: in the last conv's epilogue, or as a launch of unet_forward's own behind it
-    if ((rc = unet_forward(net, x, x_channels, cond, cond_channels, sc.t, sc.v, batch, sc.unet_ws, sc.unet_bytes, s, run))) return rc;
-    if (cdrift && (rc = euler_step_launch(cdrift, cdrift, dt, nc, s))) return rc;
-    if (traj) MI355_CHECK_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * n, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-  }
+  int rc;
+  if (net->knobs.sampler_graph && emb_table && !traj && !cdrift && n_t > 1)
+    rc = cfm_euler_graph(net, sc, x, x_channels, cond, cond_channels, t_span_host, n_t, emb_table, batch, n, workspace, s);
+  else
+    rc = cfm_euler_loop(net, sc, x, x_channels, cond, cond_channels, cdrift, t_span_host, n_t, emb_table, traj, batch, n, nc, s);
+  if (rc) return rc;
   if (u8_out) return quantize_u8_launch(x, u8_out, n, s);
   return 0;
 }

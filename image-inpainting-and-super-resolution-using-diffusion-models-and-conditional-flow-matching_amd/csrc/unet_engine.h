@@ -6,6 +6,7 @@
 #include "../../include/mi355_sampler.h"
 #include <atomic>
 #include <memory>
+#include <mutex>
 
 #include "ops.h"
 
@@ -80,6 +81,14 @@ struct mi355_unet {
   // batch size): relaxed atomic bytes, so concurrent forwards of one handle from several threads are race-free and only blur the diagnostic.
   mutable std::unique_ptr<std::atomic<char>[]> tensor_state;
   size_t tensor_state_n = 0;
+  // knobs.sampler_graph: the flow-matching Euler loop of mi355_cfm_euler_sample as instantiated hipGraphs, one per (workspace, batch, schedule,
+  // condition) the handle has been driven with (a few entries, least recently used replaced).  Guarded by graph_mu: the cache is the one piece of
+  // handle state a sampler call changes.
+  struct SamplerGraph { uint64_t key[8] = {0}; hipGraphExec_t exec = nullptr; uint64_t stamp = 0; int64_t launches = 0; };
+  mutable std::mutex graph_mu;
+  mutable std::vector<SamplerGraph> graphs;
+  mutable hipStream_t capture_stream = nullptr;
+  mutable uint64_t graph_clock = 0;
 };
 
 // Per-call options of unet_forward.  They are arguments, not handle state: a handle is immutable after unet_build, so one

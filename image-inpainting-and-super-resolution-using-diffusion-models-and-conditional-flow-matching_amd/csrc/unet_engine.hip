@@ -486,7 +486,11 @@ int unet_build(const mi355_unet_config& cfg, const float* const* params_host, in
   return 0;
 }
 
-mi355_unet::~mi355_unet() { if (err_host) (void)hipHostFree(err_host); }
+mi355_unet::~mi355_unet() {
+  if (err_host) (void)hipHostFree(err_host);
+  for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (capture_stream) (void)hipStreamDestroy(capture_stream);
+}
 
 int unet_status(const mi355_unet* net, int clear) {
   if (!net || !net->err_host) return 0;

@@ -29,14 +29,14 @@ class DebugConfigC(C.Structure):
     """mi355_debug_config (include/mi355_sampler.h): diagnostic switches, copied into a handle at creation / passed to the test ops."""
     _fields_ = [("conv_ws", C.c_int32), ("conv_small", C.c_int32), ("conv_min_wgs", C.c_int32), ("conv_stagger", C.c_int32),
                 ("conv_ablate", C.c_int32), ("conv_spin_limit", C.c_int32), ("conv_time_reps", C.c_int32), ("gn_apply_max_hw", C.c_int32),
-                ("gn_fuse", C.c_int32), ("l2_warm", C.c_int32), ("attn_fused", C.c_int32), ("gn_epilogue", C.c_int32), ("conv_pp", C.c_int32), ("conv_edge", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("gn_fuse", C.c_int32), ("l2_warm", C.c_int32), ("attn_fused", C.c_int32), ("gn_epilogue", C.c_int32), ("conv_pp", C.c_int32), ("conv_edge", C.c_int32), ("sampler_graph", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 # experiment scripts (tools/*.sh) set these; the LIBRARY reads no environment variable - the Python binding turns them into the struct
 _DEBUG_ENV = {"MI355_CONV_WS": "conv_ws", "MI355_CONV_SMALL": "conv_small", "MI355_CONV_MINWG": "conv_min_wgs", "MI355_CONV_STAGGER": "conv_stagger",
               "MI355_CONV_ABLATE": "conv_ablate", "MI355_CONV_SPIN": "conv_spin_limit", "MI355_CONV_TIME": "conv_time_reps",
               "MI355_GN_APPLY_MAXHW": "gn_apply_max_hw", "MI355_GN_FUSE": "gn_fuse", "MI355_L2_WARM": "l2_warm", "MI355_ATTN_FUSE": "attn_fused",
-              "MI355_GN_EPILOGUE": "gn_epilogue", "MI355_CONV_PP": "conv_pp", "MI355_CONV_EDGE": "conv_edge"}
+              "MI355_GN_EPILOGUE": "gn_epilogue", "MI355_CONV_PP": "conv_pp", "MI355_CONV_EDGE": "conv_edge", "MI355_SAMPLER_GRAPH": "sampler_graph"}
 
 
 def debug_config(**overrides) -> "DebugConfigC":

@@ -42,7 +42,8 @@ extern "C" {
                      * precision mode (UNetModel(use_fp16=True) runs its torso in float16, AD/image_diffusion/unet.py:559-563): bf16's speed, three more
                      * mantissa bits on every stored activation and weight; values beyond +-65504 overflow to inf as they do in the reference */
 
-/* ABI version = 100 * major + minor.  The minor number counts additive changes; 104 (round 5, later): mi355_conv2d_ex (the small-level conv's fused forms as a
+/* ABI version = 100 * major + minor.  The minor number counts additive changes; 105 (round 5, last): mi355_debug_config::sampler_graph (carved out of the
+ * reserved tail).  104 (round 5, later): mi355_conv2d_ex (the small-level conv's fused forms as a
  * test op), gn_epilogue bit 2, conv_small bit 3, conv_edge bits 2-3, conv_pp bit 5, mi355_op_profile::tile_m = -1 for plan ops that launched nothing.
  * 103 (round 5): conv_pp became a bit mask (bits 2, 3, 4: the
  * prologue and narrow forms of the ping-pong kernel), mi355_box_probe, MI355_BF16X2 and MI355_F16 added.  102 (round 4): mi355_debug_config gained conv_pp and
@@ -90,7 +91,10 @@ typedef struct mi355_debug_config {
                             *    bf16) on conv3x3_in_kernel of the same file (contraction over tap x 8 channels instead of tap x padded chunk); bit 2: that kernel
                             *    reads the caller's fp32 NCHW x (and condition) itself - no packed NHWC copy, no pack launch; bit 3: in
                             *    mi355_cfm_euler_sample the update x += dt * v happens in the last conv's epilogue (v is not stored).  Default 15 */
-  int32_t reserved[2];
+  int32_t sampler_graph;   /* 0: mi355_cfm_euler_sample enqueues its launches one by one; 1: it captures the whole loop (every network evaluation of every
+                            *    step) into ONE hipGraph per (workspace, batch, schedule, condition), instantiated once and kept on the handle, and each
+                            *    call is a copy-in, one graph launch, a copy-out.  Carved out of the reserved tail (size unchanged) */
+  int32_t reserved[1];
 } mi355_debug_config;
 void mi355_debug_defaults(mi355_debug_config* out);
 

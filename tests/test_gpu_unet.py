@@ -739,6 +739,52 @@ def test_edge_convs_take_the_samplers_copy_and_step(precision, in_ch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("in_ch", [3, 6])
+def test_sampler_loop_as_one_graph_is_bit_identical(precision, in_ch):
+    """mi355_debug_config::sampler_graph: the flow-matching Euler loop (mnist/utils_mnist2.py:118-138; cifar10/compute_fid.py:80-85 with the Euler
+    solver) recorded once as a hipGraph on the handle and replayed.  Same kernels, same arguments, same order: the final state and the uint8
+    image must be BIT-identical to the launch-by-launch loop - on the recording call, on replays with fresh x / u8 tensors, after another
+    schedule and another condition tensor took their own graphs, and beyond the cache's four entries (least recently used replaced)."""
+    from image_diffusion.unet import UNetModel, param_shapes
+    from mi355._lib import debug_config
+
+    kw = dict(image_size=32, in_channels=in_ch, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(2,),
+              channel_mult=(1, 2), num_heads=4, num_head_channels=64)
+    B = 18
+    sd = synth_state_dict(param_shapes(UNetModel(precision=precision, **kw)), 5601)
+    spans = [[0.0, 0.2, 0.5, 0.6, 1.0], [0.0, 0.5, 1.0], [0.0, 1.0], [0.0, 0.1, 1.0], [0.0, 0.3, 0.9, 1.0], [0.0, 0.2, 0.5, 0.6, 1.0]]
+    xs = [randn(5600 + i, B, 3, 32, 32).to(DEV) for i in range(3)]
+    conds = [randn(5610 + i, B, 3, 32, 32).to(DEV) for i in range(2)] if in_ch == 6 else [None, None]
+
+    def engine(graph):
+        net = UNetModel(precision=precision, **kw)
+        net.load_state_dict(sd)
+        net.debug = debug_config(sampler_graph=graph)
+        net.to(DEV)
+        return net.engine(DEV)
+
+    def run(e):
+        out = []
+        for i, sp in enumerate(spans):
+            for x in xs[: 2 if i else 3]:
+                y, _, u8 = e.cfm_euler(x.clone(), sp, cond=conds[i % 2], want_u8=True)
+                out.append((y, u8))
+        torch.cuda.synchronize(); e.check()
+        return [(y.cpu(), u.cpu()) for y, u in out]
+
+    a, b = run(engine(0)), run(engine(1))
+    assert all(torch.isfinite(y).all() for y, _ in a)
+    for (y0, u0), (y1, u1) in zip(a, b):
+        assert torch.equal(y0, y1) and torch.equal(u0, u1)
+    # the trajectory and drifting-condition forms are not graphed: they must still work on a graph-enabled handle
+    e = engine(1)
+    y, traj, _ = e.cfm_euler(xs[0].clone(), spans[0], cond=conds[0], keep_traj=True)
+    torch.cuda.synchronize()
+    assert torch.equal(traj[-1].cpu(), a[0][0]) and torch.equal(y.cpu(), a[0][0])
+
+
+@pytest.mark.gpu
 def test_groupnorm_in_place_at_16x16_matches_launch_and_read_tensor_reports_it():
     """At the 16x16 level a persistent-conv tile is a whole image, so the first conv of a ResBlock (unet.py:283-286) applies the out_layers
     GroupNorm + SiLU (unet.py:306-311; GroupNorm32 nn.py:11-13) to its own accumulators and stores the result IN PLACE (its own template
