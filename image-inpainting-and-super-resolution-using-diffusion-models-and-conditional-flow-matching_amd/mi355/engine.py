@@ -193,12 +193,38 @@ class UNetEngine:
         return {"launches": s.launches, "conv_flops": s.conv_flops, "attn_flops": s.attn_flops, "act_bytes": s.act_bytes,
                 "weight_bytes": s.weight_bytes}
 
+    def max_batch(self) -> int:
+        """Largest batch one call can take: the kernels address every activation tensor through 32-bit buffer offsets, so B x (the largest
+        tensor of the plan, per image) must stay under 4 GiB (the library refuses larger launches with "run the batch in slices")."""
+        if getattr(self, "max_batch_override", None):
+            return int(self.max_batch_override)
+        if getattr(self, "_max_batch", None) is None:
+            esz = 4 if self.precision in ("fp32", "f32") else 2
+            per_image = max([op["dst_c"] * op["dst_h"] * op["dst_h"] * esz for op in self.plan_ops() if op["dst"] >= 0] +
+                            [32 * self.image_size * self.image_size * 4])   # the samplers' fp32 scratch holds up to 32 channels
+            self._max_batch = max(1, 0xFFFF0000 // (2 * per_image))   # x2: a concat source pair / an in-flight double of the same tensor
+        return self._max_batch
+
     def cfm_euler(self, x: torch.Tensor, t_span: Sequence[float], cond: Optional[torch.Tensor] = None, keep_traj: bool = False,
                   want_u8: bool = False, cond_drift: bool = False):
         """In-place Euler integration of x over t_span (host floats).  Returns (x, traj or None, u8 or None).
         cond_drift: the condition is integrated with derivative `cond` (the concatenated-state sampler of
-        mnist/utils_mnist2.py:118-138); the caller's tensor is not modified."""
+        mnist/utils_mnist2.py:118-138); the caller's tensor is not modified.
+        A batch beyond max_batch() is integrated in slices (every image's trajectory is independent of its batch mates; the kernels chosen for a
+        slice may sum in another order than those of the whole batch would)."""
         B, Cx, Cc = self._split(x, cond)
+        mb = self.max_batch()
+        if B > mb:
+            traj = torch.empty((len(t_span),) + tuple(x.shape), device=self.device, dtype=torch.float32) if keep_traj else None
+            u8 = torch.empty(x.shape, device=self.device, dtype=torch.uint8) if want_u8 else None
+            for lo in range(0, B, mb):
+                hi = min(B, lo + mb)
+                _, tr, u = self.cfm_euler(x[lo:hi], t_span, cond[lo:hi] if cond is not None else None, keep_traj, want_u8, cond_drift)
+                if traj is not None:
+                    traj[:, lo:hi] = tr
+                if u8 is not None:
+                    u8[lo:hi] = u
+            return x, traj, u8
         ts = [float(v) for v in t_span]
         arr = (C.c_float * len(ts))(*ts)
         traj = torch.empty((len(ts),) + tuple(x.shape), device=self.device, dtype=torch.float32) if keep_traj else None

@@ -785,6 +785,31 @@ def test_sampler_loop_as_one_graph_is_bit_identical(precision, in_ch):
 
 
 @pytest.mark.gpu
+def test_cfm_euler_slices_a_batch_beyond_the_32_bit_offset_limit():
+    """The kernels address activations through 32-bit buffer offsets (a tensor of a launch stays under 4 GiB); UNetEngine.cfm_euler integrates a
+    larger batch in slices of max_batch() images.  An image's Euler trajectory does not depend on its batch mates; the library's kernel choice does
+    depend on the batch (tile sizes, split-K at the small levels), so the sliced solve equals the unsliced one to fp32 summation order, not bitwise
+    (forced here with a small limit: 23 images in slices of 8, 8, 7; fp32 mode, 2e-4)."""
+    from image_diffusion.unet import UNetModel, param_shapes
+
+    kw = dict(image_size=32, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=1, attention_resolutions=(2,),
+              channel_mult=(1, 2), num_heads=4, num_head_channels=64)
+    net = UNetModel(precision="fp32", **kw)
+    net.load_state_dict(synth_state_dict(param_shapes(net), 5701))
+    net.to(DEV)
+    e = net.engine(DEV)
+    assert 1024 <= e.max_batch() < (1 << 32) // (256 * 32 * 32 * 4)   # the largest tensor: 256 channels x 32 x 32 fp32 = 1 MiB per image
+    x, cond, sp = randn(5700, 23, 3, 32, 32).to(DEV), randn(5702, 23, 3, 32, 32).to(DEV), [0.0, 0.25, 0.5, 1.0]
+    y0, t0, u0 = e.cfm_euler(x.clone(), sp, cond=cond, keep_traj=True, want_u8=True)
+    e.max_batch_override = 8
+    y1, t1, u1 = e.cfm_euler(x.clone(), sp, cond=cond, keep_traj=True, want_u8=True)
+    torch.cuda.synchronize(); e.check()
+    assert torch.isfinite(y0).all() and y0.abs().max() > 0.1
+    assert (y0 - y1).abs().max().item() < 2e-4 and (t0 - t1).abs().max().item() < 2e-4
+    assert (u0.int() - u1.int()).abs().max().item() <= 1
+
+
+@pytest.mark.gpu
 def test_groupnorm_in_place_at_16x16_matches_launch_and_read_tensor_reports_it():
     """At the 16x16 level a persistent-conv tile is a whole image, so the first conv of a ResBlock (unet.py:283-286) applies the out_layers
     GroupNorm + SiLU (unet.py:306-311; GroupNorm32 nn.py:11-13) to its own accumulators and stores the result IN PLACE (its own template
