@@ -317,6 +317,14 @@ def main():
                "reference_launch_us": BOX_REF_US,
                "note": "boxes of the pool differ by several per cent for one build: compare lines of different boxes / rounds as value * launch_us / reference_launch_us"}
         box["value_at_reference_box"] = round(B * world * a.steps / dt * us.value / BOX_REF_US, 2)
+        # the memory side of the same calibration: a FROZEN 512-MiB -> 512-MiB copy (csrc/box_probe_hbm.hip); its buffer is freed before the profile pass
+        hw = torch.empty(int(L.mi355_box_probe_hbm_workspace_bytes()), device=dev, dtype=torch.uint8)
+        hus, hgb = C.c_float(), C.c_float()
+        _lib.check(L.mi355_box_probe_hbm(10, C.c_void_p(hw.data_ptr()), hw.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                         C.byref(hus), C.byref(hgb)), "mi355_box_probe_hbm")
+        del hw
+        box["hbm_copy"] = {"kernel": "box_probe_hbm_kernel (frozen: 512 MiB read + 512 MiB written per launch, 16-byte accesses)",
+                           "launch_us": round(hus.value, 2), "gbs": round(hgb.value / (hus.value * 1e-6), 1)}
 
     # ---- roofline of the dominant kernel, HIP events around every launch of one forward (on the launch stream) ----
     # Dominant kernel (rocprofv3 --kernel-trace, profiles/): conv3x3_ws_kernel, the warp-specialised persistent 3x3 implicit-GEMM;

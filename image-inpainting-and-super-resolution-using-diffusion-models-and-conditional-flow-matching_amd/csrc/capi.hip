@@ -467,6 +467,11 @@ int mi355_box_probe(int reps, void* workspace, int64_t workspace_bytes, void* st
   if (tflop) *tflop = (float)(box_probe_flops() * 1e-12);
   return box_probe_run(reps, workspace, workspace_bytes, S(stream), us_per_launch, clock_mhz);
 }
+int64_t mi355_box_probe_hbm_workspace_bytes(void) { return box_probe_hbm_workspace_bytes(); }
+int mi355_box_probe_hbm(int reps, void* workspace, int64_t workspace_bytes, void* stream, float* us_per_launch, float* gbytes) {
+  if (gbytes) *gbytes = (float)(box_probe_hbm_bytes() * 1e-9);
+  return box_probe_hbm_run(reps, workspace, workspace_bytes, S(stream), us_per_launch);
+}
 
 int64_t mi355_op_workspace_bytes(int batch, int max_channels, int hw) {
   const size_t c = (size_t)max_channels + 32;

@@ -194,6 +194,10 @@ int unpack_channels_launch(int dtype, const void* in, int N, int HW, int stride,
 int64_t box_probe_workspace_bytes();
 double box_probe_flops();
 int box_probe_run(int reps, void* workspace, int64_t workspace_bytes, hipStream_t s, float* us_per_launch, float* clock_mhz);
+// memory side (box_probe_hbm.hip: frozen): one launch copies 512 MiB to another 512 MiB
+int64_t box_probe_hbm_workspace_bytes();
+double box_probe_hbm_bytes();
+int box_probe_hbm_run(int reps, void* workspace, int64_t workspace_bytes, hipStream_t s, float* us_per_launch);
 
 // ---- small fp32 ops -----------------------------------------------------------------------------------
 int timestep_embedding_launch(const float* t, int B, int dim, float max_period, float* out, hipStream_t s);

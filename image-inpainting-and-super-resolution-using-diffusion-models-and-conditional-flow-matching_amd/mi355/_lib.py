@@ -148,6 +148,8 @@ SIGNATURES = {
     "mi355_op_workspace_bytes": (_I64, [_I, _I, _I]),
     "mi355_box_probe_workspace_bytes": (_I64, []),
     "mi355_box_probe": (_I, [_I, _VP, _I64, _VP, _FP, _FP, _FP]),
+    "mi355_box_probe_hbm_workspace_bytes": (_I64, []),
+    "mi355_box_probe_hbm": (_I, [_I, _VP, _I64, _VP, _FP, _FP]),
     "mi355_conv2d": (_I, [_VP, _VP, _I, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _I, C.POINTER(DebugConfigC), _VP,
                           _I64, _VP]),
     "mi355_conv2d_ex": (_I, [_VP, _VP, _I, _FP, _FP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _I, C.POINTER(DebugConfigC), _VP,

@@ -43,7 +43,7 @@ extern "C" {
                      * mantissa bits on every stored activation and weight; values beyond +-65504 overflow to inf as they do in the reference */
 
 /* ABI version = 100 * major + minor.  The minor number counts additive changes; 105 (round 5, last): mi355_debug_config::sampler_graph (carved out of the
- * reserved tail).  104 (round 5, later): mi355_conv2d_ex (the small-level conv's fused forms as a
+ * reserved tail), mi355_box_probe_hbm.  104 (round 5, later): mi355_conv2d_ex (the small-level conv's fused forms as a
  * test op), gn_epilogue bit 2, conv_small bit 3, conv_edge bits 2-3, conv_pp bit 5, mi355_op_profile::tile_m = -1 for plan ops that launched nothing.
  * 103 (round 5): conv_pp became a bit mask (bits 2, 3, 4: the
  * prologue and narrow forms of the ping-pong kernel), mi355_box_probe, MI355_BF16X2 and MI355_F16 added.  102 (round 4): mi355_debug_config gained conv_pp and
@@ -355,6 +355,11 @@ int mi355_rk_interp(float* out, const float* y0, const float* y1, const float* y
  * clock of the last launch (s_memtime / s_memrealtime), *tflop = the work of one launch.  workspace: mi355_box_probe_workspace_bytes(). */
 int64_t mi355_box_probe_workspace_bytes(void);
 int mi355_box_probe(int reps, void* workspace, int64_t workspace_bytes, void* stream, float* us_per_launch, float* clock_mhz, float* tflop);
+/* The memory side of the same calibration (csrc/box_probe_hbm.hip, FROZEN as well; ABI 105): one launch copies 512 MiB to another 512 MiB (each twice
+ * the Infinity Cache) with 16-byte accesses; two warm launches, then `reps` timed ones.  *us_per_launch = mean duration, *gbytes = bytes moved per
+ * launch (read + written) / 1e9.  workspace: mi355_box_probe_hbm_workspace_bytes() (1 GiB; contents are irrelevant and overwritten). */
+int64_t mi355_box_probe_hbm_workspace_bytes(void);
+int mi355_box_probe_hbm(int reps, void* workspace, int64_t workspace_bytes, void* stream, float* us_per_launch, float* gbytes);
 
 /* Standalone conv / attention ops on NCHW fp32 tensors for parity tests of the HIP kernels
  * (pack -> implicit-GEMM MFMA kernel -> unpack; `workspace` from mi355_op_workspace_bytes). */
